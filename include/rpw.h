@@ -1,0 +1,173 @@
+/*
+ * rpw.h -- C-ABI of the MI355X-native Recursive Patchwork ground-segmentation engine.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference package
+ * (PhilipNaveen/ROS2-Recursive-Patchwork-Implementation):
+ *
+ *   recursive_patchwork::RecursivePatchwork::filterGroundPoints
+ *       reference src/recursive_patchwork/include/recursive_patchwork.hpp:53-54  (declaration)
+ *       reference src/recursive_patchwork/src/recursive_patchwork.cpp:310-426     (definition)
+ *
+ * and it supersedes the reference's per-op accelerator seam, which crosses the
+ * host/device boundary once per op and per fit iteration:
+ *
+ *   cuda::ops::computeDistances2D / filterPointsByRadius / computeAngles / computePlaneDistances
+ *       reference src/recursive_patchwork/include/cuda_interface.hpp:59-88
+ *       reference src/recursive_patchwork/cuda/cuda_interface.cu:582-654
+ *   cuda_compute_distances_2d / cuda_filter_points_by_radius / cuda_compute_angles /
+ *   cuda_classify_points_in_patch / cuda_compute_plane_distances / cuda_classify_ground_points
+ *       reference src/recursive_patchwork/cuda/cuda_interface.cu:18-36 (forward declarations)
+ *       reference src/recursive_patchwork/cuda/cuda_wrapper.cu:139-212  (launchers)
+ *
+ * Here the seam is one call per frame (or per batch of frames): plain pointers and
+ * sizes in, labels out; the library owns device memory, streams and kernels.
+ * Nothing in this header names a torch, Eigen or STL type. No function throws;
+ * every function that can fail returns an rpw_status and leaves a message
+ * retrievable with rpw_last_error().
+ *
+ * There is NO CPU fallback behind this ABI: if no HIP device is usable,
+ * rpw_create() fails with RPW_ERR_NO_DEVICE.
+ */
+#ifndef RPW_H
+#define RPW_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPW_ABI_VERSION 1
+
+typedef enum rpw_status {
+    RPW_OK              = 0,
+    RPW_ERR_INVALID     = 1,  /* null pointer, bad size, bad config                      */
+    RPW_ERR_NO_DEVICE   = 2,  /* no usable HIP device / kernels not loadable             */
+    RPW_ERR_HIP         = 3,  /* a HIP runtime call failed (message has the HIP string)  */
+    RPW_ERR_CAPACITY    = 4,  /* batch exceeds the capacity given to rpw_create          */
+    RPW_ERR_UNSUPPORTED = 5   /* config outside the supported range (num_sectors > 128)  */
+} rpw_status;
+
+/* Mirrors recursive_patchwork::PatchworkConfig field for field
+ * (reference include/recursive_patchwork.hpp:25-36); same defaults via rpw_default_config().
+ * The ring count (8) and r_min (1.0) are hard-coded in the reference
+ * (recursive_patchwork.cpp:344-345) and are hard-coded here too. */
+typedef struct rpw_config {
+    float   sensor_height;        /* 1.2  */
+    float   max_range;            /* 150  (never read by the path, kept for layout parity) */
+    int32_t num_sectors;          /* 10   */
+    int32_t max_iter;             /* 100  */
+    int32_t adaptive_seed_height; /* 1    */
+    float   th_seeds;             /* 0.15 */
+    float   th_dist;              /* 0.2  */
+    float   th_outlier;           /* 0.08 (never read by the path) */
+    float   filtering_radius;     /* 150  */
+    int32_t max_split_depth;      /* 1000 */
+} rpw_config;
+
+/* One label per INPUT point. The reference returns two point vectors
+ * (recursive_patchwork.cpp:402-425); they are recoverable from the labels:
+ *   ground     = points labelled GROUND, input order
+ *   non-ground = points labelled NONGROUND (input order), then points labelled
+ *                OUTSIDE (input order); DROPPED points appear in neither.
+ * If stats.n_zone < 3 the reference returns {{}, cleaned} (recursive_patchwork.cpp:339-341):
+ * then non-ground = every point not DROPPED, input order. */
+enum {
+    RPW_LABEL_NONGROUND = 0,
+    RPW_LABEL_GROUND    = 1,
+    RPW_LABEL_DROPPED   = 2,  /* non-finite coordinate (cleanPoints, recursive_patchwork.cpp:19-35) */
+    RPW_LABEL_OUTSIDE   = 3   /* finite, sqrt(x^2+y^2) > filtering_radius                           */
+};
+
+typedef struct rpw_frame_stats {
+    uint32_t n_in, n_clean, n_zone, n_ground;
+    uint32_t n_patches;          /* non-empty ring x sector patches                   */
+    uint32_t n_nodes;            /* fitPlaneAndSplit calls (recursion tree nodes)     */
+    uint32_t n_splits;
+    uint32_t max_depth;
+    uint64_t total_iterations;   /* plane refits inside the loops, summed over nodes  */
+} rpw_frame_stats;
+
+/* Recursion-tree trace record (optional output, see rpw_set_trace). */
+enum {
+    RPW_NODE_FIT = 0, RPW_NODE_REJECT = 1, RPW_NODE_SMALL = 2, RPW_NODE_FLAT = 3, RPW_NODE_SPLIT = 4
+};
+typedef struct rpw_node {
+    int32_t  frame;
+    int32_t  patch;        /* ring * num_sectors + sector                        */
+    int32_t  depth;
+    uint32_t start, len;   /* slots, relative to the patch's first slot          */
+    int32_t  kind;
+    int32_t  iterations;
+    uint32_t n_inliers;
+    int32_t  split_axis;   /* SPLIT: 0 = x, 1 = y; else -1                       */
+    float    split_value;  /* SPLIT: the median                                  */
+    float    centroid[3];  /* final plane of the node (recursive_patchwork.cpp:228) */
+    float    normal[3];
+    float    residual;
+} rpw_node;
+
+typedef struct rpw_handle rpw_handle;
+
+/* kernels timed by rpw_set_profiling / rpw_get_kernel_ms */
+enum {
+    RPW_K_CLASSIFY = 0,   /* classify + per-tile histogram         */
+    RPW_K_SCAN     = 1,   /* per-frame offsets                     */
+    RPW_K_SCATTER  = 2,   /* stable scatter to patch-sorted SoA    */
+    RPW_K_FIT      = 3,   /* per-patch recursive plane fit         */
+    RPW_K_COUNT    = 4
+};
+
+void        rpw_default_config(rpw_config* cfg);
+uint32_t    rpw_abi_version(void);
+
+/* device: HIP device ordinal. max_points: capacity in points of one batch (sum over its
+ * frames). max_frames: capacity in frames of one batch. */
+rpw_status  rpw_create(const rpw_config* cfg, int device, uint32_t max_points, uint32_t max_frames,
+                       rpw_handle** out);
+void        rpw_destroy(rpw_handle* h);
+rpw_status  rpw_set_config(rpw_handle* h, const rpw_config* cfg);
+rpw_status  rpw_get_config(const rpw_handle* h, rpw_config* cfg);
+const char* rpw_last_error(const rpw_handle* h);   /* h may be NULL: message of the last failed rpw_create */
+
+/* Host-pointer, one frame, synchronous: the replacement for one filterGroundPoints call.
+ *   xyz      n x 3 floats, AoS (Point3D layout), host memory
+ *   labels   n bytes out, host memory
+ *   residual n floats out or NULL: |(p_i - c).n| against the final plane of the fitted leaf
+ *            that labelled point i; -1 for points labelled by an early-out / no patch
+ *   stats    out or NULL */
+rpw_status  rpw_segment(rpw_handle* h, const float* xyz, uint32_t n, uint8_t* labels,
+                        float* residual, rpw_frame_stats* stats);
+
+/* Device-resident batch, asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ *   d_xyz          device pointer, frames concatenated, AoS
+ *   frame_offsets  HOST array of n_frames + 1 point offsets (frame f = [off[f], off[f+1]))
+ *   d_labels       device pointer, off[n_frames] bytes
+ *   d_residual     device pointer or NULL
+ * Returns after enqueueing; results are valid once `stream` has completed. */
+rpw_status  rpw_segment_batch_device(rpw_handle* h, const float* d_xyz, const uint32_t* frame_offsets,
+                                     uint32_t n_frames, uint8_t* d_labels, float* d_residual,
+                                     void* stream);
+/* Waits for the last batch and copies its per-frame stats (n_frames records) to the host. */
+rpw_status  rpw_get_batch_stats(rpw_handle* h, rpw_frame_stats* stats, uint32_t n_frames);
+
+/* Optional recursion-tree trace of the last call (costs a little time; off by default). */
+rpw_status  rpw_set_trace(rpw_handle* h, int enable, uint32_t max_nodes);
+rpw_status  rpw_get_nodes(rpw_handle* h, rpw_node* nodes, uint32_t cap, uint32_t* n_nodes);
+
+/* Per-kernel device time, measured with HIP events on the launch stream. */
+rpw_status  rpw_set_profiling(rpw_handle* h, int enable);
+rpw_status  rpw_get_kernel_ms(rpw_handle* h, double ms[RPW_K_COUNT], uint64_t launches[RPW_K_COUNT], int reset);
+
+/* Test hooks: the device-side restatements of libm atan2f and of the 3x3 eigensolver,
+ * evaluated on the DEVICE over arrays held in host memory. */
+rpw_status  rpw_debug_angles(rpw_handle* h, const float* x, const float* y, float* angle, uint32_t n);
+rpw_status  rpw_debug_eig3(rpw_handle* h, const float* cov9, float* normal3, uint32_t n);
+/* Host evaluation of the same atan2f restatement (no device needed). */
+void        rpw_debug_angles_host(const float* x, const float* y, float* angle, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPW_H */

@@ -1,0 +1,289 @@
+"""MI355X-native Recursive Patchwork ground segmentation -- Python host side.
+
+This package holds only what the one hot path needs:
+  csrc/        hand-written gfx950 HIP kernels + the C-ABI implementation (librpw_hip.so)
+  cpp/         the drop-in C++ class recursive_patchwork::RecursivePatchwork over the C-ABI
+  workloads.py seeded synthetic LiDAR clouds (BASELINE.json configs)
+
+The Python classes below mirror the reference's C++ interface for this path
+(reference include/recursive_patchwork.hpp:25-67): PatchworkConfig field for field,
+RecursivePatchwork.filterGroundPoints / cleanPoints / setConfig / getConfig with the same
+argument meaning. They call the C-ABI (include/rpw.h) through ctypes. There is NO CPU
+fallback: if librpw_hip.so is missing or no MI355X is present the constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, asdict
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "librpw_hip.so")
+
+LABEL_NONGROUND, LABEL_GROUND, LABEL_DROPPED, LABEL_OUTSIDE = 0, 1, 2, 3
+K_CLASSIFY, K_SCAN, K_SCATTER, K_FIT, K_COUNT = 0, 1, 2, 3, 4
+KERNEL_NAMES = ("classify_hist", "scan_offsets", "stable_scatter", "patch_fit")
+
+
+class RpwError(RuntimeError):
+    pass
+
+
+class CConfig(C.Structure):
+    _fields_ = [
+        ("sensor_height", C.c_float), ("max_range", C.c_float), ("num_sectors", C.c_int32),
+        ("max_iter", C.c_int32), ("adaptive_seed_height", C.c_int32), ("th_seeds", C.c_float),
+        ("th_dist", C.c_float), ("th_outlier", C.c_float), ("filtering_radius", C.c_float),
+        ("max_split_depth", C.c_int32),
+    ]
+
+
+class CFrameStats(C.Structure):
+    _fields_ = [
+        ("n_in", C.c_uint32), ("n_clean", C.c_uint32), ("n_zone", C.c_uint32), ("n_ground", C.c_uint32),
+        ("n_patches", C.c_uint32), ("n_nodes", C.c_uint32), ("n_splits", C.c_uint32),
+        ("max_depth", C.c_uint32), ("total_iterations", C.c_uint64),
+    ]
+
+
+NODE_DTYPE = np.dtype([
+    ("frame", "<i4"), ("patch", "<i4"), ("depth", "<i4"), ("start", "<u4"), ("len", "<u4"), ("kind", "<i4"),
+    ("iterations", "<i4"), ("n_inliers", "<u4"), ("split_axis", "<i4"), ("split_value", "<f4"),
+    ("centroid", "<f4", 3), ("normal", "<f4", 3), ("residual", "<f4"),
+])
+STATS_DTYPE = np.dtype([
+    ("n_in", "<u4"), ("n_clean", "<u4"), ("n_zone", "<u4"), ("n_ground", "<u4"), ("n_patches", "<u4"),
+    ("n_nodes", "<u4"), ("n_splits", "<u4"), ("max_depth", "<u4"), ("total_iterations", "<u8"),
+])
+assert STATS_DTYPE.itemsize == C.sizeof(CFrameStats)
+
+
+@dataclass
+class PatchworkConfig:
+    """reference include/recursive_patchwork.hpp:25-36, same names and defaults."""
+    sensor_height: float = 1.2
+    max_range: float = 150.0
+    num_sectors: int = 10
+    max_iter: int = 100
+    adaptive_seed_height: bool = True
+    th_seeds: float = 0.15
+    th_dist: float = 0.2
+    th_outlier: float = 0.08
+    filtering_radius: float = 150.0
+    max_split_depth: int = 1000
+
+    def to_c(self) -> CConfig:
+        d = asdict(self)
+        d["adaptive_seed_height"] = int(bool(d["adaptive_seed_height"]))
+        return CConfig(**d)
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", PKG_DIR, "librpw_hip.so"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RpwError("building librpw_hip.so failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen librpw_hip.so; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RpwError(f"{LIB_PATH} not found: run __graft_entry__.build() / make -C {PKG_DIR}. "
+                       "There is no CPU fallback for this path.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+    L.rpw_abi_version.restype = u32
+    L.rpw_default_config.argtypes = [C.POINTER(CConfig)]
+    L.rpw_default_config.restype = None
+    L.rpw_last_error.argtypes = [vp]
+    L.rpw_last_error.restype = C.c_char_p
+    L.rpw_create.argtypes = [C.POINTER(CConfig), i32, u32, u32, C.POINTER(vp)]
+    L.rpw_create.restype = i32
+    L.rpw_destroy.argtypes = [vp]
+    L.rpw_destroy.restype = None
+    L.rpw_set_config.argtypes = [vp, C.POINTER(CConfig)]
+    L.rpw_set_config.restype = i32
+    L.rpw_get_config.argtypes = [vp, C.POINTER(CConfig)]
+    L.rpw_get_config.restype = i32
+    L.rpw_segment.argtypes = [vp, vp, u32, vp, vp, C.POINTER(CFrameStats)]
+    L.rpw_segment.restype = i32
+    L.rpw_segment_batch_device.argtypes = [vp, vp, vp, u32, vp, vp, vp]
+    L.rpw_segment_batch_device.restype = i32
+    L.rpw_get_batch_stats.argtypes = [vp, vp, u32]
+    L.rpw_get_batch_stats.restype = i32
+    L.rpw_set_trace.argtypes = [vp, i32, u32]
+    L.rpw_set_trace.restype = i32
+    L.rpw_get_nodes.argtypes = [vp, vp, u32, C.POINTER(u32)]
+    L.rpw_get_nodes.restype = i32
+    L.rpw_set_profiling.argtypes = [vp, i32]
+    L.rpw_set_profiling.restype = i32
+    L.rpw_get_kernel_ms.argtypes = [vp, vp, vp, i32]
+    L.rpw_get_kernel_ms.restype = i32
+    L.rpw_debug_angles.argtypes = [vp, vp, vp, vp, u32]
+    L.rpw_debug_angles.restype = i32
+    L.rpw_debug_eig3.argtypes = [vp, vp, vp, u32]
+    L.rpw_debug_eig3.restype = i32
+    L.rpw_debug_angles_host.argtypes = [vp, vp, vp, u32]
+    L.rpw_debug_angles_host.restype = None
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = (
+    "rpw_default_config", "rpw_abi_version", "rpw_create", "rpw_destroy", "rpw_set_config", "rpw_get_config",
+    "rpw_last_error", "rpw_segment", "rpw_segment_batch_device", "rpw_get_batch_stats", "rpw_set_trace",
+    "rpw_get_nodes", "rpw_set_profiling", "rpw_get_kernel_ms", "rpw_debug_angles", "rpw_debug_eig3",
+    "rpw_debug_angles_host",
+)
+
+
+class Engine:
+    """Thin owner of one rpw_handle (one GPU, one stream at a time)."""
+
+    def __init__(self, config: PatchworkConfig | None = None, device: int = 0,
+                 max_points: int = 1 << 21, max_frames: int = 1):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        self.config = config or PatchworkConfig()
+        cc = self.config.to_c()
+        st = self._L.rpw_create(C.byref(cc), device, max_points, max_frames, C.byref(self._h))
+        if st != 0:
+            msg = self._L.rpw_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise RpwError(f"rpw_create failed ({st}): {msg}")
+        self.max_points, self.max_frames, self.device = max_points, max_frames, device
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.rpw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != 0:
+            raise RpwError(f"rpw call failed ({st}): {self._L.rpw_last_error(self._h).decode()}")
+
+    def set_config(self, config: PatchworkConfig):
+        cc = config.to_c()
+        self._check(self._L.rpw_set_config(self._h, C.byref(cc)))
+        self.config = config
+
+    def set_trace(self, enable: bool, max_nodes: int = 1 << 16):
+        self._check(self._L.rpw_set_trace(self._h, int(enable), max_nodes))
+
+    def set_profiling(self, enable: bool):
+        self._check(self._L.rpw_set_profiling(self._h, int(enable)))
+
+    def kernel_ms(self, reset: bool = False):
+        ms = (C.c_double * K_COUNT)()
+        cnt = (C.c_uint64 * K_COUNT)()
+        self._check(self._L.rpw_get_kernel_ms(self._h, ms, cnt, int(reset)))
+        return {KERNEL_NAMES[k]: (ms[k], cnt[k]) for k in range(K_COUNT)}
+
+    def segment(self, xyz: np.ndarray, want_residual: bool = False):
+        """One frame from host memory -> (labels uint8[n], residual float32[n] | None, stats dict)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        n = len(xyz)
+        labels = np.empty(n, np.uint8)
+        res = np.empty(n, np.float32) if want_residual else None
+        st = CFrameStats()
+        self._check(self._L.rpw_segment(self._h, xyz.ctypes.data, n, labels.ctypes.data,
+                                        res.ctypes.data if res is not None else None, C.byref(st)))
+        return labels, res, {k: getattr(st, k) for k, _ in CFrameStats._fields_}
+
+    def segment_batch_device(self, d_xyz_ptr: int, frame_offsets: np.ndarray, d_labels_ptr: int,
+                             d_residual_ptr: int | None = None, stream: int | None = None):
+        """Device-resident batch (raw device pointers, e.g. torch tensor .data_ptr()); asynchronous."""
+        off = np.ascontiguousarray(frame_offsets, dtype=np.uint32)
+        self._check(self._L.rpw_segment_batch_device(self._h, d_xyz_ptr, off.ctypes.data, len(off) - 1,
+                                                     d_labels_ptr, d_residual_ptr or None, stream or None))
+
+    def batch_stats(self, n_frames: int) -> np.ndarray:
+        out = np.zeros(n_frames, STATS_DTYPE)
+        self._check(self._L.rpw_get_batch_stats(self._h, out.ctypes.data, n_frames))
+        return out
+
+    def nodes(self, cap: int = 1 << 16) -> np.ndarray:
+        out = np.zeros(cap, NODE_DTYPE)
+        cnt = C.c_uint32(0)
+        self._check(self._L.rpw_get_nodes(self._h, out.ctypes.data, cap, C.byref(cnt)))
+        if cnt.value > cap:
+            raise RpwError(f"trace overflow: {cnt.value} nodes > cap {cap}")
+        return out[: cnt.value]
+
+    def debug_angles(self, x, y):
+        x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+        a = np.empty_like(x)
+        self._check(self._L.rpw_debug_angles(self._h, x.ctypes.data, y.ctypes.data, a.ctypes.data, x.size))
+        return a
+
+    def debug_eig3(self, cov):
+        cov = np.ascontiguousarray(cov, np.float32).reshape(-1, 9)
+        out = np.empty((len(cov), 3), np.float32)
+        self._check(self._L.rpw_debug_eig3(self._h, cov.ctypes.data, out.ctypes.data, len(cov)))
+        return out
+
+
+def debug_angles_host(x, y):
+    L = load_library()
+    x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+    a = np.empty_like(x)
+    L.rpw_debug_angles_host(x.ctypes.data, y.ctypes.data, a.ctypes.data, x.size)
+    return a
+
+
+def split_by_labels(xyz: np.ndarray, labels: np.ndarray, n_zone: int):
+    """Rebuild the reference's return value {ground, non_ground} (recursive_patchwork.cpp:339-341,402-425)."""
+    xyz = np.asarray(xyz, np.float32).reshape(-1, 3)
+    if n_zone < 3:
+        return xyz[:0].copy(), xyz[labels != LABEL_DROPPED].copy()
+    g = xyz[labels == LABEL_GROUND]
+    ng = np.concatenate([xyz[labels == LABEL_NONGROUND], xyz[labels == LABEL_OUTSIDE]], axis=0)
+    return g, ng
+
+
+class RecursivePatchwork:
+    """Python mirror of recursive_patchwork::RecursivePatchwork for this path
+    (reference include/recursive_patchwork.hpp:47-67): same method names and meaning."""
+
+    def __init__(self, config: PatchworkConfig | None = None, device: int = 0, max_points: int = 1 << 21):
+        self._engine = Engine(config or PatchworkConfig(), device=device, max_points=max_points, max_frames=1)
+
+    def setConfig(self, config: PatchworkConfig):
+        self._engine.set_config(config)
+
+    def getConfig(self) -> PatchworkConfig:
+        return self._engine.config
+
+    def cleanPoints(self, points: np.ndarray) -> np.ndarray:
+        p = np.asarray(points, np.float32).reshape(-1, 3)
+        return p[np.isfinite(p).all(axis=1)]
+
+    def filterGroundPoints(self, points: np.ndarray):
+        """-> (ground_points, non_ground_points), reference order."""
+        p = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        labels, _, st = self._engine.segment(p)
+        return split_by_labels(p, labels, st["n_zone"])
+
+    def segment(self, points: np.ndarray, want_residual: bool = False):
+        """Label array view of the same call (build-side artefact)."""
+        return self._engine.segment(points, want_residual)

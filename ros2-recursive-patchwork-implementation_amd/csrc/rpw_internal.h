@@ -1,0 +1,70 @@
+// rpw_internal.h -- structures shared between the host orchestration (rpw_capi.hip) and the
+// kernels (rpw_kernels.hip). Not part of the public ABI.
+#pragma once
+
+#include <stdint.h>
+#include "../../include/rpw.h"
+#include "rpw_math.h"
+
+namespace rpw {
+
+constexpr int kWave        = 64;
+constexpr int kTileThreads = 256;                 // 4 waves
+constexpr int kTileItems   = 8;                   // points per thread
+constexpr int kTilePoints  = kTileThreads * kTileItems;   // 2048
+constexpr int kWavePoints  = kWave * kTileItems;  // 512: one wave owns a contiguous sub-tile
+constexpr int kMaxSectors  = 128;
+constexpr int kBuckets     = 64;                  // patch-size buckets for largest-first launch order
+constexpr int kStackDepth  = 48;                  // explicit recursion stack (smaller child first => <= log2(n)+2)
+
+struct PatchDesc {
+    uint32_t begin;   // absolute slot in the patch-sorted SoA arrays
+    uint32_t n;
+};
+
+struct P3 { float x, y, z; };
+
+// Everything a kernel needs, passed by value.
+struct DevParams {
+    rpw_config  cfg;
+    PolarTables tab;
+    const float* bounds;          // [S+1] sector bounds, device memory
+    int S, P, PB;                 // sectors, patches per frame (8*S), histogram row length (P+3, padded)
+
+    uint32_t        n_frames;
+    uint32_t        n_tiles;      // over all frames
+    const uint32_t* frame_off;    // [F+1] device copy
+    const uint32_t* tile_base;    // [F+1] first tile of each frame
+
+    const P3* xyz;                // input AoS
+    uint8_t*  labels;
+    float*    residual;           // may be null
+
+    uint16_t* pid;                // [N] class per input point
+    uint32_t* hist;               // [n_tiles][PB]: counts, then (after scan) frame-relative offsets
+    uint32_t* patch_begin;        // [F][P+1], frame-relative
+    PatchDesc* patches;           // [F*P]
+    uint32_t* bucket_count;       // [kBuckets]
+    uint32_t* bucket_list;        // [kBuckets][list_stride]
+    uint32_t  list_stride;
+
+    float *sx, *sy, *sz;          // patch-sorted SoA
+    uint32_t* sidx;               // original index inside the frame, per slot (never permuted)
+    float *ax, *ay, *az;          // scratch for the stable partition
+    uint8_t* mask;                // per slot: bit0 = current inlier mask, bit1 = previous mask
+
+    rpw_frame_stats* stats;       // [F]
+    rpw_node* nodes;              // trace (may be null)
+    uint32_t* node_count;
+    uint32_t  nodes_cap;
+    int       trace;
+};
+
+void launch_classify(const DevParams& p, hipStream_t s);
+void launch_scan(const DevParams& p, hipStream_t s);
+void launch_scatter(const DevParams& p, hipStream_t s);
+void launch_fit(const DevParams& p, hipStream_t s);
+void launch_debug_angles(const float* x, const float* y, float* a, uint32_t n, hipStream_t s);
+void launch_debug_eig3(const float* cov9, float* normal3, uint32_t n, hipStream_t s);
+
+} // namespace rpw

@@ -1,0 +1,44 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu() -> bool:
+    # counting devices does not initialise the GPU runtime on this image
+    try:
+        import torch
+        return torch.cuda.device_count() > 0
+    except Exception:
+        return os.path.exists("/dev/kfd")
+
+
+@pytest.fixture(scope="session")
+def has_gpu():
+    return _has_gpu()
+
+
+@pytest.fixture(scope="session")
+def engine_factory():
+    """Creates rpw engines; the HIP library must exist -- no fallback."""
+    import rpw_amd
+
+    made = []
+
+    def make(config=None, **kw):
+        e = rpw_amd.Engine(config or rpw_amd.PatchworkConfig(), **kw)
+        made.append(e)
+        return e
+
+    yield make
+    for e in made:
+        e.close()
