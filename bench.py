@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the Recursive Patchwork hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (classify+bin -> stable scatter -> per-patch recursive plane
+fit -> labels) over one batch of synthetic HDL-64-like frames that is already resident in HBM
+(BASELINE.json configs[1]/[2]: ~127 k points per frame, max_split_depth = 3). Frames are independent,
+so N GPUs run N such batches with no data-path collective ("weak" scaling); the only RCCL call is
+the trivial gather of the per-frame result records.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_POINT_FIT = 17        # 12 sorted xyz + 4 index + 1 label
+BYTES_PER_POINT_BIN = 28        # 12 xyz in + 12 sorted SoA out + 4 index out
+
+
+def make_frames(n_frames: int, rank: int):
+    """C2/C3 workload: 8 seeded HDL-64-like base frames, further frames are yaw-rotated copies."""
+    import rpw_amd
+    W = rpw_amd.workloads
+    base = [W.c2_hdl64(seed) for seed in range(min(8, n_frames))]
+    frames = []
+    for i in range(n_frames):
+        b = base[i % len(base)]
+        k = i // len(base) + 8 * rank
+        if k == 0:
+            frames.append(b)
+        else:
+            a = np.float32(0.173 * k)
+            c, s = np.float32(np.cos(a)), np.float32(np.sin(a))
+            r = np.empty_like(b)
+            r[:, 0] = b[:, 0] * c - b[:, 1] * s
+            r[:, 1] = b[:, 0] * s + b[:, 1] * c
+            r[:, 2] = b[:, 2]
+            frames.append(r)
+    return frames
+
+
+def cpu_baseline(frames, ocfg_kw, budget_s: float = 16.0):
+    """The CPU oracle (a port of the reference algorithm, stdout silent) timed on this box's host
+    cores: single-thread ms/frame and frame-parallel frames/s on all cores (ctypes releases the GIL)."""
+    import oracle_lib as O
+    from concurrent.futures import ThreadPoolExecutor
+    cfg = O.make_config(**ocfg_kw)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    O.segment(frames[0], cfg, want_residual=False, want_nodes=False)      # warm-up
+    # single thread
+    t0 = time.perf_counter(); n1 = 0
+    while time.perf_counter() - t0 < budget_s * 0.4 and n1 < 400:
+        O.segment(frames[n1 % len(frames)], cfg, want_residual=False, want_nodes=False); n1 += 1
+    t1 = time.perf_counter() - t0
+    # all cores, one frame per thread
+    def work(i):
+        O.segment(frames[i % len(frames)], cfg, want_residual=False, want_nodes=False)
+    per_round = cores * 4
+    rounds = max(1, int((budget_s * 0.6) / max(1e-3, (t1 / n1) * per_round / cores)))
+    rounds = min(rounds, 50)
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(work, range(cores)))                                   # warm-up
+        t0 = time.perf_counter()
+        list(ex.map(work, range(per_round * rounds)))
+        tp = time.perf_counter() - t0
+    nmt = per_round * rounds
+    return {
+        "value": round(nmt / tp, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": f"{nmt} frames of the bench batch, one frame per thread on {cores} threads "
+                  f"({tp:.1f} s); single thread: {1e3 * t1 / n1:.2f} ms/frame over {n1} frames",
+        "single_thread_ms_per_frame": round(1e3 * t1 / n1, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="frames in flight per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-events", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import rpw_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg_kw = dict(max_split_depth=3)                                   # configs[1]: recursion depth = 3
+    frames = make_frames(args.frames, rank)
+    offsets = np.zeros(len(frames) + 1, np.uint32)
+    offsets[1:] = np.cumsum([len(f) for f in frames])
+    total_pts = int(offsets[-1])
+    xyz_host = np.concatenate(frames, axis=0)
+
+    eng = rpw_amd.Engine(rpw_amd.PatchworkConfig(**cfg_kw), device=local_rank,
+                         max_points=total_pts, max_frames=len(frames))
+    d_xyz = torch.from_numpy(xyz_host).to(dev)
+    d_labels = torch.empty(total_pts, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+    F = len(frames)
+    gather_in = torch.zeros(F, dtype=torch.int32, device=dev)
+    gather_out = torch.zeros(F * world, dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        eng.segment_batch_device(d_xyz.data_ptr(), offsets, d_labels.data_ptr(), None, stream.cuda_stream)
+        if world > 1:
+            # trivial result gather: ground-point count per frame, from the label slab
+            dist.all_gather_into_tensor(gather_out, gather_in)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # parity spot check of the warm-up result (not timed): frame 0 against the oracle
+    st = eng.batch_stats(F)
+    import oracle_lib as O
+    if rank == 0:
+        ref = O.segment(frames[0], O.make_config(**cfg_kw), want_residual=False, want_nodes=False)
+        lab0 = d_labels[: len(frames[0])].cpu().numpy()
+        if not np.array_equal(lab0, ref.labels):
+            raise SystemExit("bench: HIP labels differ from the oracle on frame 0 -- refusing to report")
+    gather_in.copy_(torch.from_numpy(st["n_ground"].astype(np.int32)))
+
+    if not args.no_profile_events:
+        eng.set_profiling(True)
+        eng.kernel_ms(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kms = eng.kernel_ms(reset=True) if not args.no_profile_events else None
+    eng.set_profiling(False)
+
+    # single-frame latency (batch of 1), informational
+    lat_ms = None
+    if rank == 0:
+        off1 = offsets[:2].copy()
+        for _ in range(3):
+            eng.segment_batch_device(d_xyz.data_ptr(), off1, d_labels.data_ptr(), None, stream.cuda_stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            eng.segment_batch_device(d_xyz.data_ptr(), off1, d_labels.data_ptr(), None, stream.cuda_stream)
+            torch.cuda.synchronize()
+        lat_ms = 1e3 * (time.perf_counter() - t1) / reps
+
+    if rank == 0:
+        frames_total = F * world * args.steps
+        fps = frames_total / elapsed
+        out = {
+            "metric": "frames_per_sec", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "c2_hdl64 (BASELINE.json configs[1]/[2]): seeded HDL-64-like ray-cast frames, "
+                            "inputs resident in HBM, labels left in HBM",
+                "frames_per_gpu_per_step": F, "points_per_frame": int(total_pts // F),
+                "max_split_depth": 3, "max_iter": 100, "num_sectors": 10,
+            },
+            "ms_per_frame": round(1e3 * elapsed / (F * args.steps), 5),
+            "single_frame_latency_ms": None if lat_ms is None else round(lat_ms, 4),
+        }
+        if kms is not None:
+            fit_ms, fit_n = kms["patch_fit"]
+            dom = max(kms, key=lambda k: kms[k][0])
+            per = {k: (round(v[0] / max(1, v[1]), 5)) for k, v in kms.items()}
+            out["kernel_ms_per_launch"] = per
+            avg_s = (kms[dom][0] / max(1, kms[dom][1])) * 1e-3
+            bpp = BYTES_PER_POINT_FIT if dom == "patch_fit" else BYTES_PER_POINT_BIN
+            ach = bpp * total_pts / avg_s / 1e9
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                               "algorithmic_bytes_per_point": bpp}
+            bin_s = sum(kms[k][0] / max(1, kms[k][1]) for k in ("classify_hist", "scan_offsets", "stable_scatter")) * 1e-3
+            achb = BYTES_PER_POINT_BIN * total_pts / bin_s / 1e9
+            out["roofline_binning"] = {"kernels": "classify_hist+scan_offsets+stable_scatter", "bound": "hbm",
+                                       "achieved": round(achb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(achb / HBM_PEAK_GBS, 5), "traffic": None,
+                                       "algorithmic_bytes_per_point": BYTES_PER_POINT_BIN}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames, cfg_kw)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

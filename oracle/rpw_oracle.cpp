@@ -36,6 +36,9 @@
 
 namespace {
 
+// optional per-iteration trace (analysis aid): {patch, depth, iter, count, hash} as 5 x uint64
+uint64_t* g_iter_trace = nullptr; uint32_t g_iter_cap = 0, g_iter_n = 0;
+
 struct P3 { float x, y, z; };
 
 struct Plane {
@@ -360,6 +363,12 @@ std::vector<bool> fit_plane_and_split(Ctx& cx, const std::vector<P3>& pts, float
         std::vector<bool> next(n, false);
         for (size_t i = 0; i < n; ++i)
             if (plane_distance(pts[i], pl.c, pl.n) < threshold) next[i] = true;
+        if (g_iter_trace && g_iter_n < g_iter_cap) {
+            uint64_t h = 1469598103934665603ull, cnt = 0;
+            for (size_t i = 0; i < n; ++i) if (next[i]) { h = (h ^ (uint64_t)i) * 1099511628211ull; ++cnt; }
+            uint64_t* r = g_iter_trace + 5 * (size_t)g_iter_n++;
+            r[0] = (uint64_t)cx.patch; r[1] = (uint64_t)depth; r[2] = (uint64_t)iter; r[3] = cnt; r[4] = h;
+        }
         if (next == ground) break;
         ground.swap(next);
     }
@@ -440,6 +449,9 @@ void make_tables(const rpwo_config& cfg, float edges[9], std::vector<float>& bou
 } // namespace
 
 extern "C" {
+
+void rpwo_set_iter_trace(uint64_t* buf, uint32_t cap) { g_iter_trace = buf; g_iter_cap = cap; g_iter_n = 0; }
+uint32_t rpwo_iter_trace_count(void) { return g_iter_n; }
 
 int rpwo_eig3(const float* cov, float* evals, float* evecs) { return eig3(cov, evals, evecs); }
 

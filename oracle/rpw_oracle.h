@@ -98,6 +98,11 @@ int rpwo_filter_ground_points(const rpwo_config* cfg, const float* xyz, uint32_t
                               float* ground_xyz, uint32_t* n_ground,
                               float* nonground_xyz, uint32_t* n_nonground);
 
+/* analysis aid: record {patch, depth, iter, inlier count, mask hash} (5 x uint64) for every loop
+ * iteration of the following rpwo_segment calls; buf = NULL switches it off */
+void     rpwo_set_iter_trace(uint64_t* buf, uint32_t cap);
+uint32_t rpwo_iter_trace_count(void);
+
 /* pieces exposed for unit tests */
 /* Eigen 3.4.0 SelfAdjointEigenSolver<Matrix3f>(cov) restated; cov row-major 9 floats
  * (only the lower triangle is read); evals[3], evecs column-major 9 floats

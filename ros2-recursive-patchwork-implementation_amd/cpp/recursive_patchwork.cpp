@@ -1,0 +1,109 @@
+// Host side of the drop-in class: converts between the reference's vector<Point3D> interface
+// and the C-ABI (include/rpw.h). No arithmetic of the path happens here.
+#include "recursive_patchwork.hpp"
+
+#include <cmath>
+#include <iostream>
+#include <stdexcept>
+
+#include "rpw.h"
+
+namespace recursive_patchwork {
+
+namespace {
+thread_local int g_device = 0;
+
+rpw_config to_c(const PatchworkConfig& c)
+{
+    rpw_config r;
+    r.sensor_height = c.sensor_height; r.max_range = c.max_range; r.num_sectors = c.num_sectors;
+    r.max_iter = c.max_iter; r.adaptive_seed_height = c.adaptive_seed_height ? 1 : 0; r.th_seeds = c.th_seeds;
+    r.th_dist = c.th_dist; r.th_outlier = c.th_outlier; r.filtering_radius = c.filtering_radius;
+    r.max_split_depth = c.max_split_depth;
+    return r;
+}
+static_assert(sizeof(Point3D) == 3 * sizeof(float), "Point3D must be the packed AoS layout the ABI takes");
+} // namespace
+
+void RecursivePatchwork::setDevice(int device) { g_device = device; }
+
+RecursivePatchwork::RecursivePatchwork(const PatchworkConfig& config) : config_(config), device_(g_device)
+{
+    ensure(1u << 18);
+}
+
+RecursivePatchwork::~RecursivePatchwork()
+{
+    if (handle_) rpw_destroy(handle_);
+}
+
+void RecursivePatchwork::ensure(size_t n)
+{
+    if (handle_ && n <= capacity_) return;
+    size_t cap = capacity_ ? capacity_ : (1u << 18);
+    while (cap < n) cap *= 2;
+    if (handle_) { rpw_destroy(handle_); handle_ = nullptr; }
+    const rpw_config c = to_c(config_);
+    rpw_status st = rpw_create(&c, device_, (uint32_t)cap, 1, &handle_);
+    if (st != RPW_OK) {
+        handle_ = nullptr;
+        throw std::runtime_error(std::string("RecursivePatchwork: rpw_create failed: ") + rpw_last_error(nullptr));
+    }
+    capacity_ = cap;
+}
+
+void RecursivePatchwork::setConfig(const PatchworkConfig& config)
+{
+    config_ = config;
+    if (handle_) {
+        const rpw_config c = to_c(config_);
+        if (rpw_set_config(handle_, &c) != RPW_OK)
+            throw std::runtime_error(std::string("RecursivePatchwork::setConfig: ") + rpw_last_error(handle_));
+    }
+}
+
+std::vector<Point3D> RecursivePatchwork::cleanPoints(const std::vector<Point3D>& points)
+{
+    std::vector<Point3D> out;
+    out.reserve(points.size());
+    for (const Point3D& p : points)
+        if (std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z)) out.push_back(p);
+    if (out.size() < points.size())
+        std::cout << "Removed " << (points.size() - out.size()) << " points with NaN/inf values" << std::endl;
+    return out;
+}
+
+std::vector<unsigned char> RecursivePatchwork::segment(const std::vector<Point3D>& points, std::vector<float>* residuals)
+{
+    ensure(points.size());
+    std::vector<unsigned char> labels(points.size());
+    if (residuals) residuals->resize(points.size());
+    rpw_frame_stats st;
+    const rpw_status rc = rpw_segment(handle_, points.empty() ? nullptr : &points[0].x, (uint32_t)points.size(),
+                                      labels.data(), residuals ? residuals->data() : nullptr, &st);
+    if (rc != RPW_OK) throw std::runtime_error(std::string("RecursivePatchwork: rpw_segment failed: ") + rpw_last_error(handle_));
+    n_zone_last_ = st.n_zone;
+    return labels;
+}
+
+std::pair<std::vector<Point3D>, std::vector<Point3D>>
+RecursivePatchwork::filterGroundPoints(const std::vector<Point3D>& points)
+{
+    const std::vector<unsigned char> labels = segment(points, nullptr);
+    std::vector<Point3D> ground, non_ground;
+    if (n_zone_last_ < 3) {                              // {{}, cleaned_points}
+        non_ground.reserve(points.size());
+        for (size_t i = 0; i < points.size(); ++i) if (labels[i] != RPW_LABEL_DROPPED) non_ground.push_back(points[i]);
+        return {ground, non_ground};
+    }
+    ground.reserve(points.size());
+    non_ground.reserve(points.size());
+    for (size_t i = 0; i < points.size(); ++i) {
+        if (labels[i] == RPW_LABEL_GROUND) ground.push_back(points[i]);
+        else if (labels[i] == RPW_LABEL_NONGROUND) non_ground.push_back(points[i]);
+    }
+    for (size_t i = 0; i < points.size(); ++i) if (labels[i] == RPW_LABEL_OUTSIDE) non_ground.push_back(points[i]);
+    return {ground, non_ground};
+}
+
+} // namespace recursive_patchwork

@@ -1,0 +1,85 @@
+// recursive_patchwork.hpp -- drop-in header for the hot path of the reference package:
+// same namespace, type names, member names and signatures as the reference's
+// include/recursive_patchwork.hpp:18-67 for Point3D, PatchworkConfig and the parts of
+// RecursivePatchwork that sit on the path (filterGroundPoints, cleanPoints, setConfig,
+// getConfig). The public API is Eigen-free (the reference only uses Eigen in private
+// members, recursive_patchwork.hpp:73-81). The work is done on an MI355X through the
+// C-ABI in include/rpw.h; there is no CPU fallback -- construction throws
+// std::runtime_error when no device / library is usable.
+#pragma once
+
+#include <chrono>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+struct rpw_handle;
+
+namespace recursive_patchwork {
+
+struct Point3D {
+    float x, y, z;
+    Point3D() : x(0), y(0), z(0) {}
+    Point3D(float x, float y, float z) : x(x), y(y), z(z) {}
+};
+
+struct PatchworkConfig {
+    float sensor_height = 1.2f;
+    float max_range = 150.0f;
+    int num_sectors = 10;
+    int max_iter = 100;
+    bool adaptive_seed_height = true;
+    float th_seeds = 0.15f;
+    float th_dist = 0.2f;
+    float th_outlier = 0.08f;
+    float filtering_radius = 150.0f;
+    int max_split_depth = 1000;
+};
+
+class RecursivePatchwork {
+public:
+    RecursivePatchwork(const PatchworkConfig& config = PatchworkConfig{});
+    ~RecursivePatchwork();
+    RecursivePatchwork(const RecursivePatchwork&) = delete;
+    RecursivePatchwork& operator=(const RecursivePatchwork&) = delete;
+
+    // {ground_points, non_ground_points}, reference order (recursive_patchwork.cpp:402-425)
+    std::pair<std::vector<Point3D>, std::vector<Point3D>>
+    filterGroundPoints(const std::vector<Point3D>& points);
+
+    // Build-side addition: the same call as a label array (one rpw label per input point) and,
+    // optionally, per-point residuals. BASELINE.json calls this segment(PointCloud&).
+    std::vector<unsigned char> segment(const std::vector<Point3D>& points, std::vector<float>* residuals = nullptr);
+
+    std::vector<Point3D> cleanPoints(const std::vector<Point3D>& points);
+
+    void setConfig(const PatchworkConfig& config);
+    const PatchworkConfig& getConfig() const { return config_; }
+
+    // which HIP device new instances bind to (default 0); per-thread
+    static void setDevice(int device);
+
+private:
+    void ensure(size_t n);
+    PatchworkConfig config_;
+    rpw_handle* handle_ = nullptr;
+    size_t capacity_ = 0;
+    int device_ = 0;
+    unsigned n_zone_last_ = 0;
+};
+
+// same utility as the reference (recursive_patchwork.hpp:90-105)
+class Timer {
+public:
+    Timer() : start_(std::chrono::high_resolution_clock::now()) {}
+    double elapsed() const {
+        auto end = std::chrono::high_resolution_clock::now();
+        return std::chrono::duration<double>(end - start_).count();
+    }
+    void reset() { start_ = std::chrono::high_resolution_clock::now(); }
+private:
+    std::chrono::high_resolution_clock::time_point start_;
+};
+
+} // namespace recursive_patchwork

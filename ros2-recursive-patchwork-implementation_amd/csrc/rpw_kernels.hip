@@ -252,18 +252,41 @@ __global__ __launch_bounds__(kTileThreads) void stable_scatter_kernel(DevParams 
 }
 
 // ------------------------------------------------------------------------------------------
-// K4: per-patch recursive plane fit, one wavefront per (frame, patch)
+// K4: per-patch recursive plane fit. One 2-wave workgroup per (frame, patch):
+//   wave 0 = CONSUMER: runs nothing but the sequential binary32 add chains, one accumulator per
+//            lane, reading addends from an LDS ring (a dependent v_add_f32 chain retires one add
+//            per ~8 cycles on gfx950 and leaves every other issue slot empty);
+//   wave 1 = PRODUCER: streams the patch from L2/HBM with a two-chunk register prefetch, turns
+//            every slot into its addends (masked by -0.0f, an exact additive identity) and
+//            writes them transposed into the ring, two chunks ahead of the consumer.
+// Both waves share the data-parallel passes (bounding box, seeds, distances + mask compare,
+// order statistics, stable partition, labels).
 // ------------------------------------------------------------------------------------------
-constexpr int kLdw = 68;   // staging row stride in floats: 64 + 4 keeps the 6 chain lanes on distinct banks
+constexpr int kFitThreads = 128;
+constexpr int kLdw  = 68;              // ring row stride in floats: 64 + 4 keeps the 6 chain lanes on distinct banks
+constexpr int kRing = 4;               // ring slots (chunks of 64 points)
+constexpr int kSlotFloats = 6 * kLdw;
 
 struct Raw { float x, y, z; uint32_t m; };
 
+struct FitShared {
+    __attribute__((aligned(16))) float ring[kRing * kSlotFloats];
+    float bc[16];                      // broadcast: chain sums, plane
+    uint32_t red[2][8];                // per-wave partial counts / flags
+    float fred[2][8];                  // per-wave partial min / max
+    uint32_t hist[256];
+    uint32_t stk[3 * kStackDepth];
+};
+
 struct FitCtx {
     const DevParams* p;
+    FitShared* sh;
     uint32_t base;        // absolute slot of the patch's first point
-    float* stage;         // [6][kLdw]
-    int lane;
+    int lane, wave, tid;
 };
+
+// LDS-only rendezvous of the two waves: outstanding global loads (the producer's prefetch) stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ Raw load_raw(const FitCtx& cx, uint32_t s, uint32_t n, uint32_t chunk)
 {
@@ -277,39 +300,67 @@ __device__ __forceinline__ Raw load_raw(const FitCtx& cx, uint32_t s, uint32_t n
     return r;
 }
 
-// 64 sequential binary32 adds per chain lane; rows hold the addends in slot order, padded with -0.0f
-// (x + -0.0f == x for every x, so padding and masked-out slots are exact no-ops).
-__device__ __forceinline__ void chain64(float& acc, const float* row)
+#define RPW_CHAIN4(ACC, Q) { ACC += (Q).x; ACC += (Q).y; ACC += (Q).z; ACC += (Q).w; }
+
+// One chained pass over the node [s, s+n): K sequential sums, accumulator k in consumer lane k.
+// make(raw, i, out[K]) turns slot i (node-relative) into its K addends and may update the slot's mask
+// byte; post() runs once on the producer wave after its last chunk (to publish its own partials).
+// Result: sums[0..K-1] in every thread.
+template <int K, class Make, class Post>
+__device__ __forceinline__ void chain_pass(const FitCtx& cx, uint32_t s, uint32_t n, Make make, Post post, float* sums)
 {
+    float* ring = cx.sh->ring;
+    const uint32_t nch = (n + kWave - 1) / kWave;
+    if (cx.wave == 1) {
+        // ---------------- producer ----------------
+        auto fill = [&](uint32_t chunk, const Raw& r) {
+            float v[K];
+            make(r, chunk * kWave + cx.lane, v);
+            float* slot = ring + (chunk & (kRing - 1)) * kSlotFloats + cx.lane;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const float4 q = *reinterpret_cast<const float4*>(row + 4 * j);
-        acc += q.x; acc += q.y; acc += q.z; acc += q.w;
+            for (int k = 0; k < K; ++k) slot[k * kLdw] = v[k];
+        };
+        Raw ra = load_raw(cx, s, n, 0), rb = load_raw(cx, s, n, 1);
+        Raw rc = load_raw(cx, s, n, 2), rd = load_raw(cx, s, n, 3);
+        fill(0, ra);
+        if (nch > 1) fill(1, rb);
+        lds_barrier();
+        for (uint32_t t = 0; t < nch; ++t) {
+            if (t + 2 < nch) fill(t + 2, rc);
+            rc = rd;
+            rd = load_raw(cx, s, n, t + 4);
+            lds_barrier();
+        }
+        post();
+    } else {
+        // ---------------- consumer ----------------
+        // Works in half slots (32 addends = 8 float4 per lane): while one half is being added, the
+        // next half is already on its way from LDS, so the add chain never waits for a ds_read.
+        const int row = cx.lane < K ? cx.lane : K - 1;
+        const float* rowp = ring + row * kLdw;
+        float acc = 0.0f;                                 // Zero(), then += in slot order
+        lds_barrier();
+        float4 A[8], B[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const float4*>(rowp + 4 * q);
+        for (uint32_t t = 0; t < nch; ++t) {
+            const float* cur = rowp + (t & (kRing - 1)) * kSlotFloats + 32;
+            const float* nxt = rowp + ((t + 1) & (kRing - 1)) * kSlotFloats;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { B[q] = *reinterpret_cast<const float4*>(cur + 4 * q); RPW_CHAIN4(acc, A[q]) }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { A[q] = *reinterpret_cast<const float4*>(nxt + 4 * q); RPW_CHAIN4(acc, B[q]) }
+            lds_barrier();
+        }
+        if (cx.lane < K) cx.sh->bc[cx.lane] = acc;
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) sums[k] = cx.sh->bc[k];
+    __syncthreads();
 }
 
-// Generic chained pass over a node: K accumulators live in lanes 0..K-1.
-// make(raw, out[K]) turns one slot into its K addends.
-template <int K, class Make>
-__device__ __forceinline__ float chain_pass(const FitCtx& cx, uint32_t s, uint32_t n, Make make)
-{
-    float acc = 0.0f;                                     // Zero(), then += in slot order
-    const uint32_t nchunks = (n + kWave - 1) / kWave;
-    const int row = cx.lane < K ? cx.lane : K - 1;
-    Raw nxt = load_raw(cx, s, n, 0);
-    for (uint32_t c = 0; c < nchunks; ++c) {
-        const Raw cur = nxt;
-        if (c + 1 < nchunks) nxt = load_raw(cx, s, n, c + 1);
-        float v[K];
-        make(cur, v);
-#pragma unroll
-        for (int k = 0; k < K; ++k) cx.stage[k * kLdw + cx.lane] = v[k];
-        __syncthreads();
-        chain64(acc, cx.stage + row * kLdw);
-        __syncthreads();
-    }
-    return acc;                                           // lane k < K holds accumulator k
-}
+struct NoPost { __device__ __forceinline__ void operator()() const {} };
 
 __device__ __forceinline__ float plane_dist(float x, float y, float z, float cx_, float cy_, float cz_, float nx, float ny, float nz)
 {
@@ -321,17 +372,23 @@ __device__ __forceinline__ float plane_dist(float x, float y, float z, float cx_
 
 struct PlaneD { float cx, cy, cz, nx, ny, nz, residual; };
 
-// centroid + covariance + eigenvector over the slots whose mask bit `bit` is set (m = their count >= 3)
-__device__ __forceinline__ void fit_plane_masked(const FitCtx& cx, uint32_t s, uint32_t n, int bit, uint32_t m, PlaneD& pl)
+// centroid sums (sequential, slot order) over the slots whose mask bit `bit` is set
+__device__ __forceinline__ void centroid_sums(const FitCtx& cx, uint32_t s, uint32_t n, int bit, float* cs)
+{
+    chain_pass<3>(cx, s, n, [&](const Raw& r, uint32_t, float* v) {
+        const bool in = (r.m >> bit) & 1u;
+        v[0] = in ? r.x : -0.0f; v[1] = in ? r.y : -0.0f; v[2] = in ? r.z : -0.0f;
+    }, NoPost(), cs);
+}
+
+// given the centroid sums of the m >= 3 inliers (mask bit `bit`): covariance pass + eigenvector
+__device__ __forceinline__ void plane_from_sums(const FitCtx& cx, uint32_t s, uint32_t n, int bit, uint32_t m, const float* cs, PlaneD& pl)
 {
     const float NZ = -0.0f;
-    float acc = chain_pass<3>(cx, s, n, [&](const Raw& r, float* v) {
-        const bool in = (r.m >> bit) & 1u;
-        v[0] = in ? r.x : NZ; v[1] = in ? r.y : NZ; v[2] = in ? r.z : NZ;
-    });
     const float fm = (float)m;
-    const float c0 = __shfl(acc, 0) / fm, c1 = __shfl(acc, 1) / fm, c2 = __shfl(acc, 2) / fm;
-    acc = chain_pass<6>(cx, s, n, [&](const Raw& r, float* v) {
+    const float c0 = cs[0] / fm, c1 = cs[1] / fm, c2 = cs[2] / fm;
+    float cv[6];
+    chain_pass<6>(cx, s, n, [&](const Raw& r, uint32_t, float* v) {
         const bool in = (r.m >> bit) & 1u;
         const float dx = r.x - c0, dy = r.y - c1, dz = r.z - c2;
         v[0] = in ? dx * dx : NZ;   // (0,0)
@@ -340,21 +397,29 @@ __device__ __forceinline__ void fit_plane_masked(const FitCtx& cx, uint32_t s, u
         v[3] = in ? dz * dx : NZ;   // (2,0)
         v[4] = in ? dz * dy : NZ;   // (2,1)
         v[5] = in ? dz * dz : NZ;   // (2,2)
-    });
+    }, NoPost(), cv);
     const float fm1 = (float)(m - 1);
-    const float a00 = __shfl(acc, 0) / fm1, a10 = __shfl(acc, 1) / fm1, a11 = __shfl(acc, 2) / fm1;
-    const float a20 = __shfl(acc, 3) / fm1, a21 = __shfl(acc, 4) / fm1, a22 = __shfl(acc, 5) / fm1;
     pl.cx = c0; pl.cy = c1; pl.cz = c2;
-    smallest_eigenvector(a00, a10, a11, a20, a21, a22, pl.nx, pl.ny, pl.nz);
+    smallest_eigenvector(cv[0] / fm1, cv[1] / fm1, cv[2] / fm1, cv[3] / fm1, cv[4] / fm1, cv[5] / fm1, pl.nx, pl.ny, pl.nz);
 }
 
 __device__ __forceinline__ float residual_masked(const FitCtx& cx, uint32_t s, uint32_t n, int bit, uint32_t m, const PlaneD& pl)
 {
-    const float acc = chain_pass<1>(cx, s, n, [&](const Raw& r, float* v) {
+    float r1[1];
+    chain_pass<1>(cx, s, n, [&](const Raw& r, uint32_t, float* v) {
         const bool in = (r.m >> bit) & 1u;
         v[0] = in ? plane_dist(r.x, r.y, r.z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz) : -0.0f;
-    });
-    return __shfl(acc, 0) / (float)m;
+    }, NoPost(), r1);
+    return r1[0] / (float)m;
+}
+
+// combine per-wave partial counters through LDS (both waves call; returns the sums to every thread)
+__device__ __forceinline__ void combine_u32(const FitCtx& cx, uint32_t* v, int cnt)
+{
+    if (cx.lane == 0) for (int i = 0; i < cnt; ++i) cx.sh->red[cx.wave][i] = v[i];
+    __syncthreads();
+    for (int i = 0; i < cnt; ++i) v[i] = cx.sh->red[0][i] + cx.sh->red[1][i];
+    __syncthreads();
 }
 
 // monotone key: ascending unsigned order == ascending float order
@@ -362,19 +427,20 @@ __device__ __forceinline__ uint32_t float_key(float v) { const uint32_t u = __fl
 __device__ __forceinline__ float key_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 // exact order statistic: the value of rank k (0-based, ascending) among coordinate `axis` of the node
-__device__ float select_rank(const FitCtx& cx, uint32_t s, uint32_t n, int axis, uint32_t k, uint32_t* hist /*[256] LDS*/)
+__device__ float select_rank(const FitCtx& cx, uint32_t s, uint32_t n, int axis, uint32_t k)
 {
-    const float* src = axis == 0 ? cx.p->sx : (axis == 1 ? cx.p->sy : cx.p->sz);
+    const float* src = (axis == 0 ? cx.p->sx : (axis == 1 ? cx.p->sy : cx.p->sz)) + cx.base + s;
+    uint32_t* hist = cx.sh->hist;
     uint32_t prefix = 0, pmask = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int j = cx.lane; j < 256; j += kWave) hist[j] = 0;
+        for (int j = cx.tid; j < 256; j += kFitThreads) hist[j] = 0;
         __syncthreads();
-        for (uint32_t i = cx.lane; i < n; i += kWave) {
-            const uint32_t key = float_key(src[cx.base + s + i]);
+        for (uint32_t i = cx.tid; i < n; i += kFitThreads) {
+            const uint32_t key = float_key(src[i]);
             if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        // lane l owns bins 4l..4l+3
+        // every wave scans the 256 bins on its own: lane l owns bins 4l..4l+3
         const uint32_t h0 = hist[4 * cx.lane], h1 = hist[4 * cx.lane + 1], h2 = hist[4 * cx.lane + 2], h3 = hist[4 * cx.lane + 3];
         const uint32_t tot = h0 + h1 + h2 + h3;
         const uint32_t incl = wave_incl_scan(tot);
@@ -400,6 +466,7 @@ __device__ float select_rank(const FitCtx& cx, uint32_t s, uint32_t n, int axis,
 
 // libstdc++ std::partial_sort(idx, idx+3, idx+n, z[a] < z[b]) restated for "the 3 lowest z":
 // __heap_select over a 3-element max-heap; returns the three selected slots (set semantics).
+// Every wave computes the same answer on its own (no cross-wave traffic).
 __device__ void three_lowest(const FitCtx& cx, uint32_t s, uint32_t n, uint32_t sel[3])
 {
     const float* zs = cx.p->sz + cx.base + s;
@@ -407,10 +474,8 @@ __device__ void three_lowest(const FitCtx& cx, uint32_t s, uint32_t n, uint32_t 
     float z0 = zs[0], z1 = zs[1], z2 = zs[2];
     // __adjust_heap(first, 0, 3, value) + __push_heap, value = (vi, vz)
     auto adjust = [&](uint32_t vi, float vz) {
-        // larger child moves up into the hole at the root
-        int hole;
+        int hole;                                          // the larger child moves up into the root
         if (z2 < z1) { h0 = h1; z0 = z1; hole = 1; } else { h0 = h2; z0 = z2; hole = 2; }
-        // __push_heap: parent of hole is the root
         if (z0 < vz) { if (hole == 1) { h1 = h0; z1 = z0; } else { h2 = h0; z2 = z0; } h0 = vi; z0 = vz; }
         else { if (hole == 1) { h1 = vi; z1 = vz; } else { h2 = vi; z2 = vz; } }
     };
@@ -420,16 +485,14 @@ __device__ void three_lowest(const FitCtx& cx, uint32_t s, uint32_t n, uint32_t 
         const float zi = i < n ? zs[i] : 0.0f;
         unsigned long long done = 0ull;
         for (;;) {
-            const bool want = i < n && zi < z0 && !((done >> cx.lane) & 1ull) ;
-            // lanes already passed (below the current position) must not be revisited: only lanes >= cursor
-            unsigned long long cand = ballot64(want);
+            const bool want = i < n && zi < z0 && !((done >> cx.lane) & 1ull);
+            const unsigned long long cand = ballot64(want);
             if (!cand) break;
             const int l = __ffsll((long long)cand) - 1;
             const uint32_t vi = (uint32_t)__shfl((int)i, l);
             const float vz = __shfl(zi, l);
             adjust(vi, vz);
-            // every lane up to and including l has now been consumed in order
-            done |= (l == 63) ? ~0ull : ((1ull << (l + 1)) - 1ull);
+            done |= (l == 63) ? ~0ull : ((1ull << (l + 1)) - 1ull);   // lanes <= l were visited in order
         }
     }
     sel[0] = h0; sel[1] = h1; sel[2] = h2;
@@ -437,10 +500,10 @@ __device__ void three_lowest(const FitCtx& cx, uint32_t s, uint32_t n, uint32_t 
 
 struct PatchAcc { uint32_t nodes, splits, maxdepth, ground; unsigned long long iters; };
 
-__device__ __forceinline__ void emit_node(const DevParams& p, int lane, int frame, int patch, int depth, uint32_t start, uint32_t len,
+__device__ __forceinline__ void emit_node(const DevParams& p, int tid, int frame, int patch, int depth, uint32_t start, uint32_t len,
                                           int kind, int iters, uint32_t ninl, int axis, float sval, const PlaneD* pl)
 {
-    if (!p.trace || lane != 0) return;
+    if (!p.trace || tid != 0) return;
     const uint32_t slot = atomicAdd(p.node_count, 1u);
     if (slot >= p.nodes_cap) return;
     rpw_node nd;
@@ -452,12 +515,10 @@ __device__ __forceinline__ void emit_node(const DevParams& p, int lane, int fram
     p.nodes[slot] = nd;
 }
 
-__global__ __launch_bounds__(kWave) void patch_fit_kernel(DevParams p)
+__global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
 {
-    __shared__ __attribute__((aligned(16))) float stage[6 * kLdw];
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t stk[3 * kStackDepth];
-    const int lane = threadIdx.x;
+    __shared__ FitShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- block -> patch, largest size bucket first --------------------------------------------
     uint32_t linear;
@@ -475,16 +536,18 @@ __global__ __launch_bounds__(kWave) void patch_fit_kernel(DevParams p)
     const PatchDesc pd = p.patches[linear];
     const uint32_t fo = p.frame_off[frame];
 
-    FitCtx cx; cx.p = &p; cx.base = pd.begin; cx.stage = stage; cx.lane = lane;
+    FitCtx cx; cx.p = &p; cx.sh = &sh; cx.base = pd.begin; cx.lane = lane; cx.wave = wave; cx.tid = tid;
     const rpw_config& cfg = p.cfg;
+    uint32_t* stk = sh.stk;
 
     // ---- mean distance of the patch (recursive_patchwork.cpp:383-387): sequential sum of d ------
     float mean_dist;
     {
-        const float acc = chain_pass<1>(cx, 0, pd.n, [&](const Raw& r, float* v) {
+        float sum[1];
+        chain_pass<1>(cx, 0, pd.n, [&](const Raw& r, uint32_t, float* v) {
             v[0] = (r.m & 0x100u) ? sqrt_rn(r.x * r.x + r.y * r.y) : -0.0f;
-        });
-        mean_dist = __shfl(acc, 0) / (float)pd.n;
+        }, NoPost(), sum);
+        mean_dist = sum[0] / (float)pd.n;
     }
     const float rel_dist = mean_dist / cfg.filtering_radius;
     const float threshold = cfg.th_dist * (1.0f + 0.2f * rel_dist);
@@ -493,7 +556,7 @@ __global__ __launch_bounds__(kWave) void patch_fit_kernel(DevParams p)
     bool permuted = false;
 
     int sp = 0;
-    if (lane == 0) { stk[0] = 0; stk[1] = pd.n; stk[2] = 0; }
+    if (tid == 0) { stk[0] = 0; stk[1] = pd.n; stk[2] = 0; }
     sp = 1;
     __syncthreads();
 
@@ -504,34 +567,40 @@ __global__ __launch_bounds__(kWave) void patch_fit_kernel(DevParams p)
         __syncthreads();
         pa.nodes++;
         if ((uint32_t)depth > pa.maxdepth) pa.maxdepth = (uint32_t)depth;
+        const float* gx = p.sx + cx.base + s;
+        const float* gy = p.sy + cx.base + s;
+        const float* gz = p.sz + cx.base + s;
+        uint8_t* gm = p.mask + cx.base + s;
+        const uint32_t* gi = p.sidx + cx.base + s;
 
         // ---- early outs (recursive_patchwork.cpp:111-140) ---------------------------------------
         int leaf_kind = -1;            // -1: run the fit
         if (n < 3 || depth > cfg.max_split_depth) leaf_kind = RPW_NODE_REJECT;
-        float zmin_all = 0.0f;
         if (leaf_kind < 0) {
             float xmn = 3.402823466e+38f, xmx = -3.402823466e+38f, ymn = xmn, ymx = xmx, zmn = xmn, zmx = xmx;
-            for (uint32_t i = lane; i < n; i += kWave) {
-                const uint32_t g = cx.base + s + i;
-                const float x = p.sx[g], y = p.sy[g], z = p.sz[g];
+            for (uint32_t i = tid; i < n; i += kFitThreads) {
+                const float x = gx[i], y = gy[i], z = gz[i];
                 xmn = fminf(xmn, x); xmx = fmaxf(xmx, x); ymn = fminf(ymn, y); ymx = fmaxf(ymx, y);
                 zmn = fminf(zmn, z); zmx = fmaxf(zmx, z);
             }
             xmn = wave_min(xmn); xmx = wave_max(xmx); ymn = wave_min(ymn); ymx = wave_max(ymx);
             zmn = wave_min(zmn); zmx = wave_max(zmx);
-            zmin_all = zmn;
+            if (lane == 0) { float* f = sh.fred[wave]; f[0] = xmn; f[1] = xmx; f[2] = ymn; f[3] = ymx; f[4] = zmn; f[5] = zmx; }
+            __syncthreads();
+            xmn = fminf(sh.fred[0][0], sh.fred[1][0]); xmx = fmaxf(sh.fred[0][1], sh.fred[1][1]);
+            ymn = fminf(sh.fred[0][2], sh.fred[1][2]); ymx = fmaxf(sh.fred[0][3], sh.fred[1][3]);
+            zmn = fminf(sh.fred[0][4], sh.fred[1][4]); zmx = fmaxf(sh.fred[0][5], sh.fred[1][5]);
+            __syncthreads();
             const float area = (xmx - xmn) * (ymx - ymn);
             if (area < 25.0f && depth > 0) leaf_kind = RPW_NODE_SMALL;
             else if ((zmx - zmn) < 0.05f && n > 10) leaf_kind = RPW_NODE_FLAT;
         }
-        (void)zmin_all;
         if (leaf_kind >= 0) {
             if (leaf_kind != RPW_NODE_REJECT) {
-                for (uint32_t i = lane; i < n; i += kWave)
-                    p.labels[fo + p.sidx[cx.base + s + i]] = RPW_LABEL_GROUND;
+                for (uint32_t i = tid; i < n; i += kFitThreads) p.labels[fo + gi[i]] = RPW_LABEL_GROUND;
                 pa.ground += n;
             }
-            emit_node(p, lane, frame, patch, depth, s, n, leaf_kind, 0, leaf_kind == RPW_NODE_REJECT ? 0u : n, -1, 0.0f, nullptr);
+            emit_node(p, tid, frame, patch, depth, s, n, leaf_kind, 0, leaf_kind == RPW_NODE_REJECT ? 0u : n, -1, 0.0f, nullptr);
             continue;
         }
 
@@ -541,64 +610,85 @@ __global__ __launch_bounds__(kWave) void patch_fit_kernel(DevParams p)
             z_th = cfg.sensor_height + 0.2f * rel_dist;
         } else {
             const uint32_t idx = (uint32_t)(0.1f * (float)n);     // static_cast<size_t>(0.1f * size)
-            z_th = select_rank(cx, s, n, 2, idx < n ? idx : n - 1, hist) + cfg.th_seeds;
+            z_th = select_rank(cx, s, n, 2, idx < n ? idx : n - 1) + cfg.th_seeds;
         }
-        uint32_t count = 0;
-        for (uint32_t b = 0; b < n; b += kWave) {
-            const uint32_t i = b + lane;
-            const bool seed = i < n && p.sz[cx.base + s + i] < z_th;
-            if (i < n) p.mask[cx.base + s + i] = seed ? 1 : 0;
-            count += (uint32_t)__popcll(ballot64(seed));
+        // Seed pass, fused: the producer writes the seed mask (z < z_th) and hands the consumer the
+        // centroid addends of that mask in the same sweep.
+        uint32_t count;
+        float cs[4];                       // centroid sums of the current mask (+ residual sum in the fused pass)
+        {
+            uint32_t seeds = 0;
+            chain_pass<3>(cx, s, n, [&](const Raw& r, uint32_t i, float* v) {
+                const bool ok = r.m & 0x100u;
+                const bool seed = ok && r.z < z_th;
+                if (ok) gm[i] = seed ? 1 : 0;
+                seeds += (uint32_t)__popcll(ballot64(seed));
+                v[0] = seed ? r.x : -0.0f; v[1] = seed ? r.y : -0.0f; v[2] = seed ? r.z : -0.0f;
+            }, [&]() { if (lane == 0) sh.red[1][0] = seeds; }, cs);
+            count = sh.red[1][0];
+            __syncthreads();
         }
-        __syncthreads();
         if (count < 3) {
             uint32_t sel[3];
             three_lowest(cx, s, n, sel);
-            for (uint32_t i = lane; i < n; i += kWave)
-                p.mask[cx.base + s + i] = (i == sel[0] || i == sel[1] || i == sel[2]) ? 1 : 0;
+            for (uint32_t i = tid; i < n; i += kFitThreads) gm[i] = (i == sel[0] || i == sel[1] || i == sel[2]) ? 1 : 0;
             count = 3;
             __syncthreads();
+            centroid_sums(cx, s, n, 0, cs);
         }
 
         // ---- iterative refit (recursive_patchwork.cpp:186-217) ------------------------------------
+        // Per iteration two chained sweeps: (1) covariance of the current mask -> plane; (2) FUSED:
+        // distances to that plane, new mask = d < threshold (stored, history shifted up one bit),
+        // centroid addends of the NEW mask and |d| addends of the OLD mask (= the residual the
+        // reference computes after the loop, recursive_patchwork.cpp:98-104, if this iteration converges).
         PlaneD pl; pl.cx = pl.cy = pl.cz = 0.0f; pl.nx = 0.0f; pl.ny = 0.0f; pl.nz = 1.0f; pl.residual = 3.402823466e+38f;
         int iters = 0;
         int final_bit = 0;
-        bool plane_is_final = false;       // pl was fitted on exactly the final mask
+        bool have_plane = false, have_residual = false;   // pl / pl.residual belong to exactly the final mask
         for (int iter = 0; iter < cfg.max_iter; ++iter) {
             if (count < 3) break;
-            fit_plane_masked(cx, s, n, 0, count, pl);
+            plane_from_sums(cx, s, n, 0, count, cs, pl);
             ++iters;
-            // new mask = d < threshold; compare with current (bit0) and with the one before (bit1)
-            bool changed = false, differs_prev = false;
             uint32_t newcount = 0;
-            for (uint32_t b = 0; b < n; b += kWave) {
-                const uint32_t i = b + lane;
-                bool nw = false;
-                if (i < n) {
-                    const uint32_t g = cx.base + s + i;
-                    const uint32_t mk = p.mask[g];
-                    nw = plane_dist(p.sx[g], p.sy[g], p.sz[g], pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz) < threshold;
-                    const uint32_t old = mk & 1u, prev = (mk >> 1) & 1u;
-                    changed |= ((uint32_t)nw != old);
-                    differs_prev |= ((uint32_t)nw != prev);
-                    p.mask[g] = (uint8_t)((uint32_t)nw | (old << 1));
-                }
+            bool changed = false, differs_prev = false;
+            float fs[4];
+            chain_pass<4>(cx, s, n, [&](const Raw& r, uint32_t i, float* v) {
+                const bool ok = r.m & 0x100u;
+                const float d = plane_dist(r.x, r.y, r.z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
+                const bool nw = ok && d < threshold;
+                const bool old = r.m & 1u, prev = (r.m >> 1) & 1u;
+                changed |= (nw != old);
+                differs_prev |= (nw != prev);
+                if (ok) gm[i] = (uint8_t)((nw ? 1u : 0u) | ((r.m & 0x7fu) << 1));
                 newcount += (uint32_t)__popcll(ballot64(nw));
-            }
-            const bool any_changed = ballot64(changed) != 0ull;
-            const bool any_differs_prev = ballot64(differs_prev) != 0ull;
+                v[0] = nw ? r.x : -0.0f; v[1] = nw ? r.y : -0.0f; v[2] = nw ? r.z : -0.0f;
+                v[3] = old ? d : -0.0f;
+            }, [&]() {
+                const bool c = ballot64(changed) != 0ull, dp = ballot64(differs_prev) != 0ull;
+                if (lane == 0) { sh.red[1][0] = newcount; sh.red[1][1] = c ? 1u : 0u; sh.red[1][2] = dp ? 1u : 0u; }
+            }, fs);
+            newcount = sh.red[1][0];
+            const bool any_changed = sh.red[1][1] != 0, any_differs_prev = sh.red[1][2] != 0;
             __syncthreads();
-            if (!any_changed) { plane_is_final = true; break; }       // new_mask == ground_mask
+            if (!any_changed) {                                  // new_mask == ground_mask: converged
+                pl.residual = fs[3] / (float)count;
+                have_plane = true; have_residual = true;
+                break;
+            }
             const uint32_t oldcount = count;
             count = newcount;
-            plane_is_final = false;
+            cs[0] = fs[0]; cs[1] = fs[1]; cs[2] = fs[2];
             // Period-2 short cut: the new mask equals the mask two iterations ago, so the loop would
             // alternate between the two masks until max_iter; its outcome is decided by parity alone.
             if (iter >= 1 && !any_differs_prev && newcount >= 3 && iter + 1 < cfg.max_iter) {
                 const int remaining = cfg.max_iter - (iter + 1);
                 iters = cfg.max_iter;
-                if (remaining & 1) { final_bit = 1; count = oldcount; plane_is_final = true; }   // ends on the older mask: pl was fitted on it
+                if (remaining & 1) {                             // ends on the older mask: pl was fitted on it
+                    final_bit = 1; count = oldcount;
+                    pl.residual = fs[3] / (float)count;
+                    have_plane = true; have_residual = true;
+                }
                 break;
             }
         }
@@ -607,8 +697,8 @@ __global__ __launch_bounds__(kWave) void patch_fit_kernel(DevParams p)
         if (count < 3) {
             pl.cx = pl.cy = pl.cz = 0.0f; pl.nx = 0.0f; pl.ny = 0.0f; pl.nz = 1.0f; pl.residual = 3.402823466e+38f;
         } else {
-            if (!plane_is_final) fit_plane_masked(cx, s, n, final_bit, count, pl);
-            pl.residual = residual_masked(cx, s, n, final_bit, count, pl);
+            if (!have_plane) plane_from_sums(cx, s, n, final_bit, count, cs, pl);     // cs = sums of the final mask
+            if (!have_residual) pl.residual = residual_masked(cx, s, n, final_bit, count, pl);
         }
 
         // ---- split? (recursive_patchwork.cpp:231-305) ---------------------------------------------
@@ -616,43 +706,44 @@ __global__ __launch_bounds__(kWave) void patch_fit_kernel(DevParams p)
         const uint32_t min_patch = 50u + 10u * (uint32_t)depth;
         if (pl.residual > split_threshold && depth < cfg.max_split_depth && n >= min_patch) {
             // variance of x and y about the centroid of ALL node points, sequential sums
-            float acc = chain_pass<2>(cx, s, n, [&](const Raw& r, float* v) {
+            float m2[2], v2[2];
+            chain_pass<2>(cx, s, n, [&](const Raw& r, uint32_t, float* v) {
                 const bool ok = r.m & 0x100u;
                 v[0] = ok ? r.x : -0.0f; v[1] = ok ? r.y : -0.0f;
-            });
+            }, NoPost(), m2);
             const float fn = (float)n;
-            const float mx = __shfl(acc, 0) / fn, my = __shfl(acc, 1) / fn;
-            acc = chain_pass<2>(cx, s, n, [&](const Raw& r, float* v) {
+            const float mx = m2[0] / fn, my = m2[1] / fn;
+            chain_pass<2>(cx, s, n, [&](const Raw& r, uint32_t, float* v) {
                 const bool ok = r.m & 0x100u;
                 const float dx = r.x - mx, dy = r.y - my;
                 v[0] = ok ? dx * dx : -0.0f; v[1] = ok ? dy * dy : -0.0f;
-            });
-            const float var_x = __shfl(acc, 0) / fn, var_y = __shfl(acc, 1) / fn;
+            }, NoPost(), v2);
+            const float var_x = v2[0] / fn, var_y = v2[1] / fn;
             const int axis = (var_x > var_y) ? 0 : 1;
-            const float median = select_rank(cx, s, n, axis, n / 2, hist);
-            const float* src = axis == 0 ? p.sx : p.sy;
-            // stable partition: left = (val <= median) keeps order, then right keeps order
+            const float median = select_rank(cx, s, n, axis, n / 2);
+            const float* src = axis == 0 ? gx : gy;
+            // stable partition: left = (val <= median) keeps order, then right keeps order.
+            // Both waves walk every chunk (so both know the running offsets); a wave writes its own chunks.
             uint32_t nleft = 0;
             for (uint32_t b = 0; b < n; b += kWave) {
                 const uint32_t i = b + lane;
-                nleft += (uint32_t)__popcll(ballot64(i < n && src[cx.base + s + i] <= median));
+                nleft += (uint32_t)__popcll(ballot64(i < n && src[i] <= median));
             }
             uint32_t lo = 0, ro = 0;
-            for (uint32_t b = 0; b < n; b += kWave) {
+            for (uint32_t b = 0, c = 0; b < n; b += kWave, ++c) {
                 const uint32_t i = b + lane;
                 const bool ok = i < n;
-                float x = 0, y = 0, z = 0;
-                if (ok) { const uint32_t g = cx.base + s + i; x = p.sx[g]; y = p.sy[g]; z = p.sz[g]; }
-                const bool left = ok && (axis == 0 ? x : y) <= median;
+                const float val = ok ? src[i] : 0.0f;
+                const bool left = ok && val <= median;
                 const unsigned long long ml = ballot64(left), mr = ballot64(ok && !left);
-                if (ok) {
+                if (ok && (int)(c & 1u) == wave) {
                     const uint32_t d = cx.base + s + (left ? lo + (uint32_t)mbcnt64(ml) : nleft + ro + (uint32_t)mbcnt64(mr));
-                    p.ax[d] = x; p.ay[d] = y; p.az[d] = z;
+                    p.ax[d] = gx[i]; p.ay[d] = gy[i]; p.az[d] = gz[i];
                 }
                 lo += (uint32_t)__popcll(ml); ro += (uint32_t)__popcll(mr);
             }
             __syncthreads();
-            for (uint32_t i = lane; i < n; i += kWave) {
+            for (uint32_t i = tid; i < n; i += kFitThreads) {
                 const uint32_t g = cx.base + s + i;
                 p.sx[g] = p.ax[g]; p.sy[g] = p.ay[g]; p.sz[g] = p.az[g];
             }
@@ -660,10 +751,10 @@ __global__ __launch_bounds__(kWave) void patch_fit_kernel(DevParams p)
             permuted = true;
             pa.splits++;
             pa.iters += (unsigned long long)iters;
-            emit_node(p, lane, frame, patch, depth, s, n, RPW_NODE_SPLIT, iters, count, axis, median, &pl);
+            emit_node(p, tid, frame, patch, depth, s, n, RPW_NODE_SPLIT, iters, count, axis, median, &pl);
             // children inherit mean_dist; process the smaller one first (bounded stack)
             const uint32_t nright = n - nleft;
-            if (lane == 0) {
+            if (tid == 0) {
                 const bool left_small = nleft <= nright;
                 const uint32_t big_s = left_small ? s + nleft : s, big_n = left_small ? nright : nleft;
                 const uint32_t sm_s = left_small ? s : s + nleft, sm_n = left_small ? nleft : nright;
@@ -677,22 +768,21 @@ __global__ __launch_bounds__(kWave) void patch_fit_kernel(DevParams p)
 
         // ---- FIT leaf: labels (and residuals) -----------------------------------------------------
         pa.iters += (unsigned long long)iters;
-        for (uint32_t i = lane; i < n; i += kWave) {
-            const uint32_t g = cx.base + s + i;
-            const uint32_t orig = p.sidx[g];
-            if ((p.mask[g] >> final_bit) & 1u) p.labels[fo + orig] = RPW_LABEL_GROUND;
+        for (uint32_t i = tid; i < n; i += kFitThreads) {
+            const uint32_t orig = gi[i];
+            if ((gm[i] >> final_bit) & 1u) p.labels[fo + orig] = RPW_LABEL_GROUND;
             if (p.residual) {
                 float x, y, z;
                 if (permuted) { const P3 q = p.xyz[fo + orig]; x = q.x; y = q.y; z = q.z; }
-                else { x = p.sx[g]; y = p.sy[g]; z = p.sz[g]; }
+                else { x = gx[i]; y = gy[i]; z = gz[i]; }
                 p.residual[fo + orig] = plane_dist(x, y, z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
             }
         }
         pa.ground += count;
-        emit_node(p, lane, frame, patch, depth, s, n, RPW_NODE_FIT, iters, count, -1, 0.0f, &pl);
+        emit_node(p, tid, frame, patch, depth, s, n, RPW_NODE_FIT, iters, count, -1, 0.0f, &pl);
     }
 
-    if (lane == 0) {
+    if (tid == 0) {
         rpw_frame_stats* st = p.stats + frame;
         atomicAdd(&st->n_ground, pa.ground);
         atomicAdd(&st->n_nodes, pa.nodes);
@@ -743,7 +833,7 @@ void launch_fit(const DevParams& p, hipStream_t s)
 {
     const uint32_t grid = p.n_frames * (uint32_t)p.P;
     if (grid == 0) return;
-    hipLaunchKernelGGL(patch_fit_kernel, dim3(grid), dim3(kWave), 0, s, p);
+    hipLaunchKernelGGL(patch_fit_kernel, dim3(grid), dim3(kFitThreads), 0, s, p);
 }
 void launch_debug_angles(const float* x, const float* y, float* a, uint32_t n, hipStream_t s)
 {
