@@ -22,7 +22,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "librpw_hip.so")
+LIB_PATH = os.environ.get("RPW_LIB", os.path.join(PKG_DIR, "librpw_hip.so"))
 
 LABEL_NONGROUND, LABEL_GROUND, LABEL_DROPPED, LABEL_OUTSIDE = 0, 1, 2, 3
 K_CLASSIFY, K_SCAN, K_SCATTER, K_FIT, K_COUNT = 0, 1, 2, 3, 4

@@ -126,6 +126,11 @@ __device__ __forceinline__ int size_bucket(uint32_t n)
 
 __global__ __launch_bounds__(kTileThreads) void scan_offsets_kernel(DevParams p)
 {
+    // One block per frame; thread c owns class c (patch ids, then the 3 special classes). Every load
+    // address is known up front, so the per-class walks over the tiles pipeline instead of paying one
+    // L2 round trip per step.
+    extern __shared__ uint32_t lds_u32[];
+    uint32_t* tot = lds_u32;                  // [PB] per-class totals, then exclusive prefix (patch_begin)
     __shared__ uint32_t red[8];
     const int tid = threadIdx.x;
     const uint32_t f = blockIdx.x;
@@ -133,50 +138,56 @@ __global__ __launch_bounds__(kTileThreads) void scan_offsets_kernel(DevParams p)
     const uint32_t nt = p.tile_base[f + 1] - t0;
     const uint32_t fo = p.frame_off[f];
     const uint32_t nf = p.frame_off[f + 1] - fo;
+    const int C = p.P + 3;
+    uint32_t* base = p.hist + (size_t)t0 * p.PB;
+
+    for (int c = tid; c < C; c += kTileThreads) {
+        uint32_t acc = 0;
+#pragma unroll 8
+        for (uint32_t t = 0; t < nt; ++t) acc += base[(size_t)t * p.PB + c];
+        tot[c] = acc;
+    }
+    __syncthreads();
+    // exclusive prefix over the patch classes (chunks of 256), block-wide
     uint32_t running = 0, npatches = 0;
-    for (int c = 0; c < p.P; ++c) {
-        uint32_t carry = 0;
-        for (uint32_t b0 = 0; b0 < nt; b0 += kTileThreads) {
-            const uint32_t t = b0 + tid;
-            uint32_t* cell = p.hist + (size_t)(t0 + t) * p.PB + c;
-            const uint32_t v = t < nt ? *cell : 0u;
-            uint32_t total;
-            const uint32_t ex = block_excl_scan(v, red, total);
-            if (t < nt) *cell = running + carry + ex;
-            carry += total;
-        }
-        if (tid == 0) {
-            p.patch_begin[(size_t)f * (p.P + 1) + c] = running;
-            PatchDesc d; d.begin = fo + running; d.n = carry;
+    for (int c0 = 0; c0 < p.P; c0 += kTileThreads) {
+        const int c = c0 + tid;
+        const uint32_t v = c < p.P ? tot[c] : 0u;
+        uint32_t total, nz_total;
+        const uint32_t ex = block_excl_scan(v, red, total);
+        (void)block_excl_scan(v > 0 ? 1u : 0u, red, nz_total);
+        if (c < p.P) {
+            const uint32_t begin = running + ex;
+            tot[c] = begin;
+            p.patch_begin[(size_t)f * (p.P + 1) + c] = begin;
+            PatchDesc d; d.begin = fo + begin; d.n = v;
             p.patches[(size_t)f * p.P + c] = d;
-            if (carry > 0) {
-                const int b = size_bucket(carry);
+            if (v > 0) {
+                const int b = size_bucket(v);
                 const uint32_t pos = atomicAdd(&p.bucket_count[b], 1u);
                 p.bucket_list[(size_t)b * p.list_stride + pos] = f * (uint32_t)p.P + (uint32_t)c;
             }
         }
-        if (carry > 0) ++npatches;
-        running += carry;
+        running += total; npatches += nz_total;
     }
-    // special classes: totals only
-    uint32_t special[3];
-    for (int c = 0; c < 3; ++c) {
-        uint32_t acc = 0;
-        for (uint32_t b0 = 0; b0 < nt; b0 += kTileThreads) {
-            const uint32_t t = b0 + tid;
-            const uint32_t v = t < nt ? p.hist[(size_t)(t0 + t) * p.PB + p.P + c] : 0u;
-            uint32_t total;
-            (void)block_excl_scan(v, red, total);
-            acc += total;
+    __syncthreads();
+    // running offsets per class over the tiles, in tile (= input) order
+    for (int c = tid; c < p.P; c += kTileThreads) {
+        uint32_t off = tot[c];
+#pragma unroll 8
+        for (uint32_t t = 0; t < nt; ++t) {
+            uint32_t* cell = base + (size_t)t * p.PB + c;
+            const uint32_t v = *cell;
+            *cell = off;
+            off += v;
         }
-        special[c] = acc;
     }
     if (tid == 0) {
         p.patch_begin[(size_t)f * (p.P + 1) + p.P] = running;
         rpw_frame_stats st;
         st.n_in = nf;
-        st.n_clean = nf - special[2];
-        st.n_zone = st.n_clean - special[1];
+        st.n_clean = nf - tot[p.P + 2];
+        st.n_zone = st.n_clean - tot[p.P + 1];
         st.n_ground = 0; st.n_patches = npatches; st.n_nodes = 0; st.n_splits = 0; st.max_depth = 0;
         st.total_iterations = 0;
         p.stats[f] = st;
@@ -283,7 +294,19 @@ struct FitCtx {
     FitShared* sh;
     uint32_t base;        // absolute slot of the patch's first point
     int lane, wave, tid;
+#if defined(RPW_STAMPS)       /* diagnostic build only: where block 0 spends its cycles */
+    mutable unsigned long long t_loop = 0, t_bar = 0, n_chunks = 0, n_pass = 0, t_pro = 0, t_epi = 0;
+#endif
 };
+
+#if defined(RPW_STAMPS)
+__device__ __forceinline__ unsigned long long stamp() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+#define RPW_T(var) const unsigned long long var = stamp();
+#define RPW_ACC(field, a, b) cx.field += (b) - (a);
+#else
+#define RPW_T(var)
+#define RPW_ACC(field, a, b)
+#endif
 
 // LDS-only rendezvous of the two waves: outstanding global loads (the producer's prefetch) stay in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -295,12 +318,16 @@ __device__ __forceinline__ Raw load_raw(const FitCtx& cx, uint32_t s, uint32_t n
     if (i < n) {
         const uint32_t g = cx.base + s + i;
         r.x = cx.p->sx[g]; r.y = cx.p->sy[g]; r.z = cx.p->sz[g];
-        r.m = (uint32_t)cx.p->mask[g] | 0x100u;          // bit 8 = slot exists
+        r.m = (uint32_t)cx.p->mask[g];                   // raw byte: nothing here may depend on a load's result
     }
     return r;
 }
 
+#if defined(RPW_EXP_NOADD)      /* timing experiment only: results are wrong */
+#define RPW_CHAIN4(ACC, Q) { ACC += (Q).x; asm volatile("" :: "v"((Q).y), "v"((Q).z), "v"((Q).w)); }
+#else
 #define RPW_CHAIN4(ACC, Q) { ACC += (Q).x; ACC += (Q).y; ACC += (Q).z; ACC += (Q).w; }
+#endif
 
 // One chained pass over the node [s, s+n): K sequential sums, accumulator k in consumer lane k.
 // make(raw, i, out[K]) turns slot i (node-relative) into its K addends and may update the slot's mask
@@ -314,23 +341,36 @@ __device__ __forceinline__ void chain_pass(const FitCtx& cx, uint32_t s, uint32_
     if (cx.wave == 1) {
         // ---------------- producer ----------------
         auto fill = [&](uint32_t chunk, const Raw& r) {
+#if defined(RPW_EXP_NOFILL)     /* timing experiment only: results are wrong */
+            if (chunk > 1) return;
+#endif
             float v[K];
-            make(r, chunk * kWave + cx.lane, v);
+            const uint32_t i = chunk * kWave + cx.lane;
+            make(r, i, i < n, v);
             float* slot = ring + (chunk & (kRing - 1)) * kSlotFloats + cx.lane;
 #pragma unroll
             for (int k = 0; k < K; ++k) slot[k * kLdw] = v[k];
         };
-        Raw ra = load_raw(cx, s, n, 0), rb = load_raw(cx, s, n, 1);
-        Raw rc = load_raw(cx, s, n, 2), rd = load_raw(cx, s, n, 3);
-        fill(0, ra);
-        if (nch > 1) fill(1, rb);
+        RPW_T(tp0)
+        Raw r0 = load_raw(cx, s, n, 0), r1 = load_raw(cx, s, n, 1);
+        fill(0, r0); r0 = load_raw(cx, s, n, 2);
+        if (nch > 1) fill(1, r1);
+        r1 = load_raw(cx, s, n, 3);
         lds_barrier();
-        for (uint32_t t = 0; t < nch; ++t) {
-            if (t + 2 < nch) fill(t + 2, rc);
-            rc = rd;
-            rd = load_raw(cx, s, n, t + 4);
-            lds_barrier();
+        RPW_T(tp1) RPW_ACC(t_pro, tp0, tp1)
+        // step t fills chunk t+2 from the register set loaded two steps earlier (no register rotation:
+        // a copy of a just-loaded register would force a wait on that load)
+        for (uint32_t t = 0; t < nch; t += 2) {
+            if (t + 2 < nch) fill(t + 2, r0);
+            r0 = load_raw(cx, s, n, t + 4);
+            { RPW_T(tb0) lds_barrier(); RPW_T(tb1) RPW_ACC(t_bar, tb0, tb1) }
+            if (t + 1 < nch) {
+                if (t + 3 < nch) fill(t + 3, r1);
+                r1 = load_raw(cx, s, n, t + 5);
+                { RPW_T(tb0) lds_barrier(); RPW_T(tb1) RPW_ACC(t_bar, tb0, tb1) }
+            }
         }
+        RPW_T(tp2) RPW_ACC(t_loop, tp1, tp2)
         post();
     } else {
         // ---------------- consumer ----------------
@@ -339,7 +379,9 @@ __device__ __forceinline__ void chain_pass(const FitCtx& cx, uint32_t s, uint32_
         const int row = cx.lane < K ? cx.lane : K - 1;
         const float* rowp = ring + row * kLdw;
         float acc = 0.0f;                                 // Zero(), then += in slot order
+        RPW_T(tc0)
         lds_barrier();
+        RPW_T(tc1) RPW_ACC(t_pro, tc0, tc1)
         float4 A[8], B[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const float4*>(rowp + 4 * q);
@@ -347,17 +389,25 @@ __device__ __forceinline__ void chain_pass(const FitCtx& cx, uint32_t s, uint32_
             const float* cur = rowp + (t & (kRing - 1)) * kSlotFloats + 32;
             const float* nxt = rowp + ((t + 1) & (kRing - 1)) * kSlotFloats;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { B[q] = *reinterpret_cast<const float4*>(cur + 4 * q); RPW_CHAIN4(acc, A[q]) }
+            for (int q = 0; q < 8; ++q) { B[q] = *reinterpret_cast<const float4*>(cur + 4 * q); RPW_CHAIN4(acc, A[q]) __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { A[q] = *reinterpret_cast<const float4*>(nxt + 4 * q); RPW_CHAIN4(acc, B[q]) }
+            for (int q = 0; q < 8; ++q) { A[q] = *reinterpret_cast<const float4*>(nxt + 4 * q); RPW_CHAIN4(acc, B[q]) __builtin_amdgcn_sched_barrier(0); }
+            RPW_T(tb0)
             lds_barrier();
+            RPW_T(tb1) RPW_ACC(t_bar, tb0, tb1)
         }
+        RPW_T(tc2) RPW_ACC(t_loop, tc1, tc2)
+#if defined(RPW_STAMPS)
+        cx.n_chunks += nch; cx.n_pass += 1;
+#endif
         if (cx.lane < K) cx.sh->bc[cx.lane] = acc;
     }
+    RPW_T(te0)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; ++k) sums[k] = cx.sh->bc[k];
     __syncthreads();
+    RPW_T(te1) RPW_ACC(t_epi, te0, te1)
 }
 
 struct NoPost { __device__ __forceinline__ void operator()() const {} };
@@ -375,8 +425,8 @@ struct PlaneD { float cx, cy, cz, nx, ny, nz, residual; };
 // centroid sums (sequential, slot order) over the slots whose mask bit `bit` is set
 __device__ __forceinline__ void centroid_sums(const FitCtx& cx, uint32_t s, uint32_t n, int bit, float* cs)
 {
-    chain_pass<3>(cx, s, n, [&](const Raw& r, uint32_t, float* v) {
-        const bool in = (r.m >> bit) & 1u;
+    chain_pass<3>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
+        const bool in = ok && ((r.m >> bit) & 1u);
         v[0] = in ? r.x : -0.0f; v[1] = in ? r.y : -0.0f; v[2] = in ? r.z : -0.0f;
     }, NoPost(), cs);
 }
@@ -388,8 +438,8 @@ __device__ __forceinline__ void plane_from_sums(const FitCtx& cx, uint32_t s, ui
     const float fm = (float)m;
     const float c0 = cs[0] / fm, c1 = cs[1] / fm, c2 = cs[2] / fm;
     float cv[6];
-    chain_pass<6>(cx, s, n, [&](const Raw& r, uint32_t, float* v) {
-        const bool in = (r.m >> bit) & 1u;
+    chain_pass<6>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
+        const bool in = ok && ((r.m >> bit) & 1u);
         const float dx = r.x - c0, dy = r.y - c1, dz = r.z - c2;
         v[0] = in ? dx * dx : NZ;   // (0,0)
         v[1] = in ? dy * dx : NZ;   // (1,0)
@@ -406,8 +456,8 @@ __device__ __forceinline__ void plane_from_sums(const FitCtx& cx, uint32_t s, ui
 __device__ __forceinline__ float residual_masked(const FitCtx& cx, uint32_t s, uint32_t n, int bit, uint32_t m, const PlaneD& pl)
 {
     float r1[1];
-    chain_pass<1>(cx, s, n, [&](const Raw& r, uint32_t, float* v) {
-        const bool in = (r.m >> bit) & 1u;
+    chain_pass<1>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
+        const bool in = ok && ((r.m >> bit) & 1u);
         v[0] = in ? plane_dist(r.x, r.y, r.z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz) : -0.0f;
     }, NoPost(), r1);
     return r1[0] / (float)m;
@@ -519,6 +569,7 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
 {
     __shared__ FitShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    RPW_T(t_kernel0)
 
     // ---- block -> patch, largest size bucket first --------------------------------------------
     uint32_t linear;
@@ -544,8 +595,8 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
     float mean_dist;
     {
         float sum[1];
-        chain_pass<1>(cx, 0, pd.n, [&](const Raw& r, uint32_t, float* v) {
-            v[0] = (r.m & 0x100u) ? sqrt_rn(r.x * r.x + r.y * r.y) : -0.0f;
+        chain_pass<1>(cx, 0, pd.n, [&](const Raw& r, uint32_t, bool ok, float* v) {
+            v[0] = ok ? sqrt_rn(r.x * r.x + r.y * r.y) : -0.0f;
         }, NoPost(), sum);
         mean_dist = sum[0] / (float)pd.n;
     }
@@ -618,8 +669,7 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
         float cs[4];                       // centroid sums of the current mask (+ residual sum in the fused pass)
         {
             uint32_t seeds = 0;
-            chain_pass<3>(cx, s, n, [&](const Raw& r, uint32_t i, float* v) {
-                const bool ok = r.m & 0x100u;
+            chain_pass<3>(cx, s, n, [&](const Raw& r, uint32_t i, bool ok, float* v) {
                 const bool seed = ok && r.z < z_th;
                 if (ok) gm[i] = seed ? 1 : 0;
                 seeds += (uint32_t)__popcll(ballot64(seed));
@@ -653,11 +703,10 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
             uint32_t newcount = 0;
             bool changed = false, differs_prev = false;
             float fs[4];
-            chain_pass<4>(cx, s, n, [&](const Raw& r, uint32_t i, float* v) {
-                const bool ok = r.m & 0x100u;
+            chain_pass<4>(cx, s, n, [&](const Raw& r, uint32_t i, bool ok, float* v) {
                 const float d = plane_dist(r.x, r.y, r.z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
                 const bool nw = ok && d < threshold;
-                const bool old = r.m & 1u, prev = (r.m >> 1) & 1u;
+                const bool old = ok && (r.m & 1u), prev = ok && ((r.m >> 1) & 1u);
                 changed |= (nw != old);
                 differs_prev |= (nw != prev);
                 if (ok) gm[i] = (uint8_t)((nw ? 1u : 0u) | ((r.m & 0x7fu) << 1));
@@ -707,14 +756,12 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
         if (pl.residual > split_threshold && depth < cfg.max_split_depth && n >= min_patch) {
             // variance of x and y about the centroid of ALL node points, sequential sums
             float m2[2], v2[2];
-            chain_pass<2>(cx, s, n, [&](const Raw& r, uint32_t, float* v) {
-                const bool ok = r.m & 0x100u;
+            chain_pass<2>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
                 v[0] = ok ? r.x : -0.0f; v[1] = ok ? r.y : -0.0f;
             }, NoPost(), m2);
             const float fn = (float)n;
             const float mx = m2[0] / fn, my = m2[1] / fn;
-            chain_pass<2>(cx, s, n, [&](const Raw& r, uint32_t, float* v) {
-                const bool ok = r.m & 0x100u;
+            chain_pass<2>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
                 const float dx = r.x - mx, dy = r.y - my;
                 v[0] = ok ? dx * dx : -0.0f; v[1] = ok ? dy * dy : -0.0f;
             }, NoPost(), v2);
@@ -782,6 +829,13 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
         emit_node(p, tid, frame, patch, depth, s, n, RPW_NODE_FIT, iters, count, -1, 0.0f, &pl);
     }
 
+#if defined(RPW_STAMPS)
+    if (blockIdx.x == 0 && lane == 0 && p.nodes) {
+        RPW_T(t_kernel1)
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.nodes + (p.nodes_cap - 8)) + 8 * wave;
+        d[0] = t_kernel1 - t_kernel0; d[1] = cx.t_loop; d[2] = cx.t_bar; d[3] = cx.n_chunks; d[4] = cx.n_pass; d[5] = cx.t_pro; d[6] = cx.t_epi; d[7] = pd.n;
+    }
+#endif
     if (tid == 0) {
         rpw_frame_stats* st = p.stats + frame;
         atomicAdd(&st->n_ground, pa.ground);
@@ -822,7 +876,7 @@ void launch_classify(const DevParams& p, hipStream_t s)
 void launch_scan(const DevParams& p, hipStream_t s)
 {
     if (p.n_frames == 0) return;
-    hipLaunchKernelGGL(scan_offsets_kernel, dim3(p.n_frames), dim3(kTileThreads), 0, s, p);
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(p.n_frames), dim3(kTileThreads), (size_t)p.PB * 4, s, p);
 }
 void launch_scatter(const DevParams& p, hipStream_t s)
 {
