@@ -88,6 +88,28 @@ def cpu_baseline(frames, ocfg_kw, budget_s: float = 16.0):
     }
 
 
+def gather_counts(local_counts, world):
+    """The path's only collective: all-gather of the per-frame result record (ground-point counts).
+    RCCL on the GPU box (backend "nccl"), gloo in the CPU test."""
+    import torch
+    import torch.distributed as dist
+    if world <= 1:
+        return local_counts.clone()
+    out = torch.empty(local_counts.numel() * world, dtype=local_counts.dtype, device=local_counts.device)
+    dist.all_gather_into_tensor(out, local_counts)
+    return out
+
+
+def max_over_ranks(elapsed: float, device):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,7 +159,6 @@ def main():
     stream = streams[0]
     F = len(frames)
     gather_in = torch.zeros(F, dtype=torch.int32, device=dev)
-    gather_out = torch.zeros(F * world, dtype=torch.int32, device=dev) if world > 1 else None
     step_no = [0]
 
     def step():
@@ -147,7 +168,7 @@ def main():
                                         streams[k].cuda_stream)
         if world > 1:
             # trivial result gather: ground-point count per frame (RCCL all-gather of F int32 per rank)
-            dist.all_gather_into_tensor(gather_out, gather_in)
+            gather_counts(gather_in, world)
 
     for _ in range(args.warmup):
         step()
@@ -178,10 +199,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dev)
     kms = None
     if not args.no_profile_events:
         kms = {}

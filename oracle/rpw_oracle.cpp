@@ -476,7 +476,7 @@ float rpwo_angle(float x, float y) { return angle_of(x, y); }
 int rpwo_segment(const rpwo_config* cfg, const float* xyz, uint32_t n, uint8_t* labels,
                  float* residual, rpwo_node* nodes, uint32_t nodes_cap, rpwo_stats* stats)
 {
-    if (!cfg || (!xyz && n) || !labels) return 1;
+    if (!cfg || (n && (!xyz || !labels))) return 1;
     rpwo_stats local;
     rpwo_stats* st = stats ? stats : &local;
     std::memset(st, 0, sizeof(*st));

@@ -148,6 +148,8 @@ __global__ __launch_bounds__(kTileThreads) void scan_offsets_kernel(DevParams p)
         tot[c] = acc;
     }
     __syncthreads();
+    // zone < 3: the reference returns {{}, cleaned} before looking at any patch (recursive_patchwork.cpp:339-341)
+    const bool zone_too_small = (nf - tot[p.P + 2] - tot[p.P + 1]) < 3u;
     // exclusive prefix over the patch classes (chunks of 256), block-wide
     uint32_t running = 0, npatches = 0;
     for (int c0 = 0; c0 < p.P; c0 += kTileThreads) {
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(kTileThreads) void scan_offsets_kernel(DevParams p)
             p.patch_begin[(size_t)f * (p.P + 1) + c] = begin;
             PatchDesc d; d.begin = fo + begin; d.n = v;
             p.patches[(size_t)f * p.P + c] = d;
-            if (v > 0) {
+            if (v > 0 && !zone_too_small) {
                 const int b = size_bucket(v);
                 const uint32_t pos = atomicAdd(&p.bucket_count[b], 1u);
                 p.bucket_list[(size_t)b * p.list_stride + pos] = f * (uint32_t)p.P + (uint32_t)c;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(kTileThreads) void scan_offsets_kernel(DevParams p)
         st.n_in = nf;
         st.n_clean = nf - tot[p.P + 2];
         st.n_zone = st.n_clean - tot[p.P + 1];
-        st.n_ground = 0; st.n_patches = npatches; st.n_nodes = 0; st.n_splits = 0; st.max_depth = 0;
+        st.n_ground = 0; st.n_patches = zone_too_small ? 0u : npatches; st.n_nodes = 0; st.n_splits = 0; st.max_depth = 0;
         st.total_iterations = 0;
         p.stats[f] = st;
     }

@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# PyTorch ships its own copy of the HIP runtime. When a test shares a process between torch and
+# librpw_hip.so (device-resident batches), torch must be loaded FIRST so that both resolve to one
+# runtime; the other order leaves torch with "No HIP GPUs are available".
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

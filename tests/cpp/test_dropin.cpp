@@ -1,0 +1,72 @@
+// Drop-in check of the C++ surface: the calls the reference's own test makes
+// (reference test/test_recursive_patchwork.cpp:51-98,146-164), against
+// recursive_patchwork::RecursivePatchwork backed by the HIP library. Seeded instead of random_device.
+#include "recursive_patchwork.hpp"
+
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+using namespace recursive_patchwork;
+
+static std::vector<Point3D> synthetic(size_t n, unsigned seed)
+{
+    std::vector<Point3D> pts; pts.reserve(n);
+    std::mt19937 gen(seed);
+    std::normal_distribution<float> gz(0.0f, 0.05f);
+    std::uniform_real_distribution<float> gxy(-50.0f, 50.0f), oxy(-30.0f, 30.0f), oz(0.5f, 3.0f);
+    const size_t ng = static_cast<size_t>(n * 0.7);
+    for (size_t i = 0; i < ng; ++i) { Point3D p; p.x = gxy(gen); p.y = gxy(gen); p.z = gz(gen); pts.push_back(p); }
+    for (size_t i = ng; i < n; ++i) { Point3D p; p.x = oxy(gen); p.y = oxy(gen); p.z = oz(gen); pts.push_back(p); }
+    return pts;
+}
+
+int main()
+{
+    // testBasicFunctionality
+    auto points = synthetic(5000, 1);
+    PatchworkConfig config;
+    config.sensor_height = 1.2f; config.filtering_radius = 50.0f; config.num_sectors = 8; config.max_iter = 50;
+    RecursivePatchwork patchwork(config);
+    auto [ground, non_ground] = patchwork.filterGroundPoints(points);
+    assert(ground.size() + non_ground.size() <= points.size());
+    assert(ground.size() > 0);
+    assert(non_ground.size() > 0);
+    std::printf("basic: %zu ground, %zu non-ground\n", ground.size(), non_ground.size());
+
+    // label view of the same call must agree with the two vectors
+    std::vector<float> res;
+    auto labels = patchwork.segment(points, &res);
+    size_t g = 0;
+    for (unsigned char l : labels) g += (l == 1);
+    assert(g == ground.size());
+    assert(res.size() == points.size());
+
+    // non-finite points are dropped, points beyond the radius come last in non_ground
+    points.push_back(Point3D(NAN, 0, 0));
+    points.push_back(Point3D(500.0f, 0, 0));
+    auto r2 = patchwork.filterGroundPoints(points);
+    assert(r2.first.size() + r2.second.size() == points.size() - 1);
+    assert(r2.second.back().x == 500.0f);
+    assert(patchwork.cleanPoints(points).size() == points.size() - 1);
+
+    // setConfig / getConfig, default config, bigger cloud (capacity growth), timing like testPerformance
+    RecursivePatchwork def;
+    auto big = synthetic(300000, 7);
+    Timer t;
+    auto r3 = def.filterGroundPoints(big);
+    std::printf("perf: %zu points in %.3f ms\n", big.size(), t.elapsed() * 1e3);
+    assert(r3.first.size() > 0 && r3.first.size() + r3.second.size() == big.size());
+    PatchworkConfig c2 = def.getConfig(); c2.num_sectors = 12; def.setConfig(c2);
+    assert(def.getConfig().num_sectors == 12);
+    auto r4 = def.filterGroundPoints(big);
+    assert(r4.first.size() + r4.second.size() == big.size());
+
+    // empty input: both empty
+    auto r5 = def.filterGroundPoints({});
+    assert(r5.first.empty() && r5.second.empty());
+    std::printf("drop-in OK\n");
+    return 0;
+}

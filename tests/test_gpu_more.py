@@ -1,0 +1,152 @@
+"""More GPU parity: batches, edge cases, full-size configs, golden fixtures, the C++ drop-in class."""
+import json
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import rpw_amd
+from rpw_amd import workloads as W
+from parity_util import cfg_pair, assert_frame_parity, sort_nodes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=lambda c: f"{c['workload']}-{c['seed']}-{len(c['config'])}")
+def test_hip_against_golden_fixtures(engine_factory, case):
+    """BASELINE.json's full sizes (C1 20k ... C5 1.09M points) against the committed fixtures."""
+    xyz = W.make(case["workload"], case["seed"])
+    assert crc(xyz) == case["input_crc32"]
+    kw = dict(case["config"])
+    if "adaptive_seed_height" in kw:
+        kw["adaptive_seed_height"] = bool(kw["adaptive_seed_height"])
+    eng = engine_factory(rpw_amd.PatchworkConfig(**kw), max_points=len(xyz), max_frames=1)
+    labels, res, st = eng.segment(xyz, want_residual=True)
+    assert crc(labels) == case["labels_crc32"]
+    for k, v in case["stats"].items():
+        assert int(st[k]) == v, k
+    # residuals: within 1e-5 of the oracle is the bar; bit equality is expected and reported
+    if crc(res) != case["residual_crc32"]:
+        ref = O.segment(xyz, O.make_config(**case["config"]), want_nodes=False).residual
+        ok = ref >= 0
+        assert np.array_equal(res < 0, ~ok) and np.abs(res[ok] - ref[ok]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("name,kw", [("c5", dict(max_split_depth=6)), ("c5", dict(max_split_depth=6, max_iter=0)),
+                                     ("c4", dict(max_iter=3, max_split_depth=8, th_dist=0.05))])
+def test_full_size_parity_with_trace(engine_factory, name, kw):
+    xyz = W.make(name, 0)
+    pc, oc = cfg_pair(**kw)
+    eng = engine_factory(pc, max_points=len(xyz), max_frames=1)
+    eng.set_trace(True, 1 << 18)
+    labels, res, st = eng.segment(xyz, want_residual=True)
+    assert_frame_parity(xyz, labels, res, st, eng.nodes(1 << 18), oc, tag=f"{name}/{kw}")
+
+
+def test_batch_of_mixed_frames_device_resident(engine_factory):
+    """One launch over a batch of different frames (incl. an empty, a tiny and a non-finite frame)."""
+    import torch
+    frames = [W.c2_hdl64(5), W.c1_test_cloud(3), np.zeros((0, 3), np.float32), W.c4_iac_fused(1)[:50000],
+              np.array([[1, 2, 0], [np.nan, 0, 0]], np.float32), W.c2_hdl64(6)[::3],
+              np.full((100, 3), np.inf, np.float32), W.c1_test_cloud(4, n=2049)]
+    pc, oc = cfg_pair(max_split_depth=3)
+    off = np.zeros(len(frames) + 1, np.uint32); off[1:] = np.cumsum([len(f) for f in frames])
+    eng = engine_factory(pc, max_points=int(off[-1]), max_frames=len(frames))
+    eng.set_trace(True, 1 << 17)
+    d = torch.from_numpy(np.concatenate(frames)).cuda()
+    lab = torch.empty(int(off[-1]), dtype=torch.uint8, device="cuda")
+    res = torch.empty(int(off[-1]), dtype=torch.float32, device="cuda")
+    for rep in range(2):       # second run reuses every work buffer
+        eng.segment_batch_device(d.data_ptr(), off, lab.data_ptr(), res.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = eng.batch_stats(len(frames))
+    nodes = eng.nodes(1 << 17)
+    L, R = lab.cpu().numpy(), res.cpu().numpy()
+    for f, xyz in enumerate(frames):
+        sl = slice(int(off[f]), int(off[f + 1]))
+        assert_frame_parity(xyz, L[sl], R[sl], {k: st[k][f] for k in st.dtype.names}, nodes[nodes["frame"] == f], oc, tag=f"frame{f}")
+
+
+def test_edge_cases(engine_factory):
+    pc, oc = cfg_pair()
+    eng = engine_factory(pc, max_points=1 << 16, max_frames=1)
+    rs = np.random.RandomState(0)
+    cases = {
+        "empty": np.zeros((0, 3), np.float32),
+        "one": np.array([[3, 4, 0]], np.float32),
+        "two": np.array([[3, 4, 0], [5, 1, 0.1]], np.float32),
+        "all_nan": np.full((10, 3), np.nan, np.float32),
+        "zone_lt_3": np.array([[300, 0, 0], [2, 2, 0], [np.nan, 1, 1], [400, 3, 0]], np.float32),
+        "inside_rmin": (rs.uniform(-0.5, 0.5, (200, 3))).astype(np.float32),
+        "on_radius": np.array([[150, 0, 0], [0, 150, 0], [-150, 0, 0], [90, 120, 0], [1, 0, 0], [0, -1, 0]], np.float32),
+        "axes": np.array([[x, y, 0.01 * i] for i, (x, y) in enumerate([(5, 0), (0, 5), (-5, 0), (0, -5), (5, -0.0), (5, 1e-30), (5, -1e-30)] * 5)], np.float32),
+        "identical": np.tile(np.array([[10, 10, -1]], np.float32), (500, 1)),
+        "flat": np.column_stack([rs.uniform(5, 6, 300), rs.uniform(5, 6, 300), np.full(300, 0.01)]).astype(np.float32),
+        "ragged_tile": W.c1_test_cloud(8, n=2047),
+        "quantized": (np.round(W.c1_test_cloud(9, n=5000) * 4) / 4).astype(np.float32),
+        "huge_coords": (W.c1_test_cloud(10, n=3000) * np.float32(1e18)).astype(np.float32),
+        "denormal": (W.c1_test_cloud(12, n=1000) * np.float32(1e-42)).astype(np.float32),
+    }
+    for name, xyz in cases.items():
+        labels, res, st = eng.segment(xyz, want_residual=True)
+        assert_frame_parity(xyz, labels, res, st, None, oc, check_nodes=False, tag=name)
+        g, ng = rpw_amd.split_by_labels(xyz, labels, st["n_zone"])
+        g2, ng2 = O.filter_ground_points(xyz, oc)
+        assert np.array_equal(g, g2, equal_nan=True) and np.array_equal(ng, ng2, equal_nan=True), name
+
+
+def test_forced_deep_recursion_and_ties(engine_factory):
+    """Quantised coordinates give many equal split values (left child may keep every point)."""
+    xyz = (np.round(W.c2_hdl64(7)[::2] * 2) / 2).astype(np.float32)
+    total_splits = 0
+    for kw in (dict(max_iter=0, max_split_depth=40), dict(max_iter=2, th_dist=0.02, max_split_depth=12),
+               dict(max_iter=1, adaptive_seed_height=False, th_dist=0.05, max_split_depth=6)):
+        pc, oc = cfg_pair(**kw)
+        eng = engine_factory(pc, max_points=len(xyz), max_frames=1)
+        eng.set_trace(True, 1 << 18)
+        labels, res, st = eng.segment(xyz, want_residual=True)
+        assert_frame_parity(xyz, labels, res, st, eng.nodes(1 << 18), oc, tag=str(kw))
+        total_splits += int(st["n_splits"])
+    assert total_splits > 0
+
+
+def test_period_two_shortcut_is_exact(engine_factory):
+    """max_iter parity decides which of two alternating masks survives: odd and even max_iter."""
+    xyz = W.c2_hdl64(2)
+    for mi in (7, 8, 30, 31, 100):
+        pc, oc = cfg_pair(max_split_depth=3, max_iter=mi, th_dist=0.05)
+        eng = engine_factory(pc, max_points=len(xyz), max_frames=1)
+        labels, res, st = eng.segment(xyz, want_residual=True)
+        assert_frame_parity(xyz, labels, res, st, None, oc, check_nodes=False, tag=f"max_iter={mi}")
+
+
+def test_run_to_run_determinism_and_python_mirror(engine_factory):
+    xyz = W.c2_hdl64(4)
+    rp = rpw_amd.RecursivePatchwork(rpw_amd.PatchworkConfig(max_split_depth=3), max_points=len(xyz))
+    g1, n1 = rp.filterGroundPoints(xyz)
+    g2, n2 = rp.filterGroundPoints(xyz)
+    assert np.array_equal(g1, g2) and np.array_equal(n1, n2)
+    og, on = O.filter_ground_points(xyz, O.make_config(max_split_depth=3))
+    assert np.array_equal(g1, og) and np.array_equal(n1, on)
+    assert len(rp.cleanPoints(np.array([[1, 2, 3], [np.nan, 0, 0]], np.float32))) == 1
+
+
+def test_cpp_dropin_program(tmp_path):
+    """Compile and run tests/cpp/test_dropin.cpp against the in-tree libraries."""
+    pkg = rpw_amd.PKG_DIR
+    subprocess.check_call(["make", "-C", pkg, "-s", "librecursive_patchwork.so"])
+    exe = str(tmp_path / "test_dropin")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(pkg, "cpp"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), "-o", exe,
+                           "-L", pkg, "-lrecursive_patchwork", "-lrpw_hip", f"-Wl,-rpath,{pkg}"])
+    out = subprocess.check_output([exe], text=True, timeout=300)
+    assert "drop-in OK" in out

@@ -1,0 +1,79 @@
+"""CPU tests of the host logic that sits between the C-ABI and the reference's vector interface,
+of the workload generators, and of bench.py's multi-GPU plumbing (gloo, world_size 2)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import rpw_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_split_by_labels_reproduces_reference_order():
+    cfg = O.make_config()
+    xyz = rpw_amd.workloads.c1_test_cloud(seed=9, n=4000)
+    xyz = np.concatenate([xyz, np.array([[400, 0, 0], [np.nan, 0, 0], [0.2, 0.2, 0]], np.float32), xyz[:50] * 10])
+    r = O.segment(xyz, cfg)
+    g, ng = rpw_amd.split_by_labels(xyz, r.labels, r.stats["n_zone"])
+    g2, ng2 = O.filter_ground_points(xyz, cfg)
+    assert np.array_equal(g, g2) and np.array_equal(ng, ng2)
+    # zone < 3: {{}, cleaned}
+    tiny = np.array([[300, 0, 0], [2, 2, 0], [np.nan, 1, 1]], np.float32)
+    r = O.segment(tiny, cfg)
+    g, ng = rpw_amd.split_by_labels(tiny, r.labels, r.stats["n_zone"])
+    assert len(g) == 0 and np.array_equal(ng, tiny[:2])
+
+
+def test_workloads_are_deterministic_and_shaped():
+    W = rpw_amd.workloads
+    a, b = W.c2_hdl64(0), W.c2_hdl64(0)
+    assert np.array_equal(a, b) and a.dtype == np.float32 and 120000 < len(a) < 135000
+    assert not np.array_equal(W.c2_hdl64(1)[:1000], a[:1000])
+    c4 = W.c4_iac_fused(0)
+    d = np.hypot(c4[:, 0], c4[:, 1])
+    assert 280000 < len(c4) < 310000 and d.min() > 2.5        # ego-radius removal, lidar_fusion.cpp:184-187
+    assert 19000 < len(W.c1_test_cloud(1)) <= 20000
+
+
+def test_config_mirror_field_for_field():
+    c = rpw_amd.PatchworkConfig(num_sectors=7, adaptive_seed_height=False).to_c()
+    o = O.make_config(num_sectors=7, adaptive_seed_height=0)
+    for name, _ in rpw_amd.CConfig._fields_:
+        assert getattr(c, name) == getattr(o, name), name
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = bench.make_frames(2, rank)                      # each rank: its own frames (weak scaling)
+    counts = torch.tensor([len(f) for f in frames], dtype=torch.int32)
+    out = bench.gather_counts(counts, world)                 # the "trivial result gather"
+    t = bench.max_over_ranks(0.5 + rank, torch.device("cpu"))
+    q.put((rank, out.tolist(), t, [int(rpw_amd.workloads.crc32(f)) for f in frames]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_gpu_plumbing_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, g0, t0, c0), (r1, g1, t1, c1) = res
+    assert g0 == g1 and len(g0) == 4                         # every rank sees every frame's record
+    assert t0 == t1 == 1.5                                   # MAX over ranks
+    assert c0 != c1                                          # ranks process different frames

@@ -1,0 +1,154 @@
+"""CPU tests of the ORACLE: golden fixtures, analytic pins, and an independent numpy restatement.
+
+The reference holds no golden vectors for this path and cannot be built here (needs <Eigen/Dense>),
+so the oracle is 'parity unpinned' against the reference; these tests pin it against (i) the fixtures
+minted by tests/golden/make_golden.py, (ii) analytic facts, (iii) numpy fp64 eigh, (iv) an independent
+numpy/float32 restatement of the whole path.
+"""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import np_emulation as E
+import rpw_amd
+
+W = rpw_amd.workloads
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=lambda c: f"{c['workload']}-{c['seed']}-{len(c['config'])}")
+def test_golden(case):
+    if case["n"] > 400000 and os.environ.get("RPW_FAST_TESTS"):
+        pytest.skip("large case skipped in fast mode")
+    xyz = W.make(case["workload"], case["seed"])
+    assert len(xyz) == case["n"] and crc(xyz) == case["input_crc32"], "workload generator drifted"
+    r = O.segment(xyz, O.make_config(**case["config"]), nodes_cap=max(1 << 16, len(xyz)))
+    assert crc(r.labels) == case["labels_crc32"]
+    assert np.bincount(r.labels, minlength=4).tolist() == case["label_hist"]
+    assert crc(r.residual) == case["residual_crc32"]
+    for k, v in case["stats"].items():
+        assert int(r.stats[k]) == v, k
+    nodes = r.nodes[np.lexsort([r.nodes["depth"], r.nodes["start"], r.nodes["patch"]])]
+    for got, want in zip(nodes[:4], case["first_nodes"]):
+        assert int(got["patch"]) == want["patch"] and int(got["iterations"]) == want["iterations"]
+        assert np.allclose(got["centroid"], want["centroid"], atol=0, rtol=0)
+        assert np.allclose(got["normal"], want["normal"], atol=0, rtol=0)
+
+
+def test_tables_match_reference_expressions():
+    e, b = O.tables(O.make_config())
+    # ring edges at R = 150
+    assert np.allclose(e, [1, 1.8707, 3.4996, 6.5469, 12.247, 22.912, 42.862, 80.183, 150], rtol=2e-4)
+    assert e[0] == 1.0 and e[8] == 150.0
+    sa = np.float32(2.0 * np.pi / 10)
+    assert np.array_equal(b, (np.arange(11, dtype=np.float32) * sa).astype(np.float32))
+
+
+def test_eig3_analytic_and_fp64():
+    # zero matrix -> scale 1, Q = I, normal (1,0,0)
+    info, ev, Q = O.eig3(np.zeros((3, 3), np.float32))
+    assert info == 0 and np.array_equal(ev, [0, 0, 0]) and np.array_equal(Q, np.eye(3, dtype=np.float32))
+    # diagonal, already sorted / unsorted
+    info, ev, Q = O.eig3(np.diag([3.0, 1.0, 2.0]).astype(np.float32))
+    assert np.allclose(ev, [1, 2, 3]) and abs(abs(Q[1, 0]) - 1) < 1e-6
+    # rank-1
+    v = np.array([1.0, 2.0, 2.0], np.float32) / 3
+    info, ev, Q = O.eig3(np.outer(v, v).astype(np.float32))
+    assert np.allclose(ev, [0, 0, 1], atol=1e-6) and abs(abs(Q[:, 2] @ v) - 1) < 1e-5
+    # random covariances against numpy fp64
+    rs = np.random.RandomState(0)
+    worst = 0.0
+    for _ in range(3000):
+        pts = rs.normal(size=(12, 3)) * rs.uniform(0.01, 20, 3)
+        c = np.cov(pts.T).astype(np.float32)
+        info, ev, Q = O.eig3(c)
+        assert info == 0
+        w = np.linalg.eigvalsh(c.astype(np.float64))
+        worst = max(worst, np.abs(ev - w).max() / max(1e-30, np.abs(w).max()))
+        assert np.abs(Q.T @ Q - np.eye(3)).max() < 1e-5
+        assert np.abs(c @ Q - Q * ev).max() < 1e-5 * max(1.0, np.abs(c).max())
+    assert worst < 1e-5
+
+
+def test_eig3_oracle_equals_numpy_restatement_bitwise():
+    rs = np.random.RandomState(1)
+    for _ in range(400):
+        pts = rs.normal(size=(9, 3)) * rs.uniform(0.001, 50, 3)
+        c = np.cov(pts.T).astype(np.float32)
+        i1, e1, q1 = O.eig3(c)
+        i2, e2, q2 = E.eig3(c)
+        assert i1 == i2 and np.array_equal(e1.view(np.uint32), e2.view(np.uint32))
+        assert np.array_equal(q1.view(np.uint32), q2.view(np.uint32))
+
+
+def test_fit_plane_exact_plane():
+    rs = np.random.RandomState(2)
+    xy = rs.uniform(-10, 10, (500, 2))
+    z = 0.1 * xy[:, 0] - 0.05 * xy[:, 1] + 1.0
+    c, n, res = O.fit_plane(np.column_stack([xy, z]).astype(np.float32))
+    want = np.array([-0.1, 0.05, 1.0]); want /= np.linalg.norm(want)
+    assert np.allclose(n, want, atol=1e-4) and res < 1e-5 and n[2] > 0
+    c2, n2, r2 = O.fit_plane(np.zeros((2, 3), np.float32))
+    assert np.array_equal(n2, [0, 0, 1]) and r2 == np.float32(3.402823466e+38)
+
+
+CFG_PY = dict(sensor_height=1.2, num_sectors=10, max_iter=100, adaptive_seed_height=1, th_seeds=0.15,
+              th_dist=0.2, filtering_radius=150.0, max_split_depth=1000)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(max_iter=0), dict(adaptive_seed_height=0), dict(sensor_height=-5.0),
+                                dict(sensor_height=0.3, th_dist=0.1, max_iter=50, num_sectors=8, filtering_radius=50.0)],
+                         ids=["default", "forced-split", "percentile-seeds", "three-lowest", "node-thresholds"])
+def test_numpy_restatement_agrees_exactly(kw):
+    xyz = W.c1_test_cloud(seed=11, n=6000)
+    cfg = dict(CFG_PY); cfg.update(kw)
+    lab, st = E.segment(xyz, cfg)
+    r = O.segment(xyz, O.make_config(**kw))
+    assert np.array_equal(lab, r.labels)
+    assert st["nodes"] == r.stats["n_nodes"] and st["iters"] == r.stats["total_iterations"] and st["splits"] == r.stats["n_splits"]
+
+
+def test_numpy_restatement_hdl64_subsample():
+    xyz = W.c2_hdl64(3)[::6]
+    cfg = dict(CFG_PY); cfg.update(max_split_depth=3, sensor_height=-1.4)
+    lab, st = E.segment(xyz, cfg)
+    r = O.segment(xyz, O.make_config(max_split_depth=3, sensor_height=-1.4))
+    assert np.array_equal(lab, r.labels) and st["iters"] == r.stats["total_iterations"]
+
+
+def test_reference_quirks():
+    cfg = O.make_config()
+    # d < 1 (inside ring_edges[0]) and d == R exactly: in the zone, in no patch -> non-ground (RP.cpp:344,373-374)
+    base = W.c1_test_cloud(seed=5, n=3000)
+    extra = np.array([[0.5, 0.1, 0.0], [150.0, 0.0, 0.0], [200.0, 0.0, 0.0], [np.nan, 0, 0], [0, np.inf, 0]], np.float32)
+    xyz = np.concatenate([base, extra])
+    r = O.segment(xyz, cfg)
+    assert r.labels[-5] == 0 and r.labels[-4] == 0 and r.labels[-3] == 3 and r.labels[-2] == 2 and r.labels[-1] == 2
+    assert r.stats["n_clean"] == len(xyz) - 2 and r.stats["n_zone"] == len(xyz) - 3
+    # zone < 3 -> {{}, cleaned} in cleaned order (RP.cpp:339-341)
+    tiny = np.array([[300, 0, 0], [2, 2, 0], [np.nan, 1, 1], [3, 3, 0]], np.float32)
+    g, ng = O.filter_ground_points(tiny, cfg)
+    assert len(g) == 0 and np.array_equal(ng, tiny[[0, 1, 3]])
+    # empty / all non-finite
+    g, ng = O.filter_ground_points(np.zeros((0, 3), np.float32), cfg)
+    assert len(g) == 0 and len(ng) == 0
+    g, ng = O.filter_ground_points(np.full((4, 3), np.nan, np.float32), cfg)
+    assert len(g) == 0 and len(ng) == 0
+    # reference order of the two vectors: ground / non-ground in zone order, outside points appended
+    g, ng = O.filter_ground_points(xyz, cfg)
+    lab = r.labels
+    assert np.array_equal(g, xyz[lab == 1])
+    assert np.array_equal(ng, np.concatenate([xyz[lab == 0], xyz[lab == 3]]))
+    # -0.0 angle stays in sector 0; negative y just below the axis wraps to the last sector
+    assert O.lib().rpwo_angle(1.0, -0.0) == 0.0 and np.signbit(np.float32(O.lib().rpwo_angle(1.0, -0.0)))
+    a = O.lib().rpwo_angle(1.0, -1e-6)
+    assert 6.28 < a < 6.2832
