@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -43,6 +44,7 @@ struct rpw_handle {
     int stage_next = 0;
 
     uint16_t* d_pid = nullptr;
+    uint8_t* d_pid8 = nullptr;
     uint32_t* d_hist = nullptr;
     uint32_t max_tiles = 0;
     uint32_t* d_patch_begin = nullptr;
@@ -94,7 +96,7 @@ rpw_status fail(rpw_handle* h, rpw_status st, const char* fmt, ...)
 void free_device(rpw_handle* h)
 {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(h->d_bounds); F(h->d_offsets); F(h->d_pid); F(h->d_hist); F(h->d_patch_begin); F(h->d_patches);
+    F(h->d_bounds); F(h->d_offsets); F(h->d_pid); F(h->d_pid8); F(h->d_hist); F(h->d_patch_begin); F(h->d_patches);
     F(h->d_ctrl); F(h->d_bucket_list); F(h->d_sx); F(h->d_sy); F(h->d_sz); F(h->d_ax); F(h->d_ay); F(h->d_az);
     F(h->d_sidx); F(h->d_mask); F(h->d_stats); F(h->d_nodes); F(h->d_in); F(h->d_labels); F(h->d_res);
     for (int i = 0; i < kStageSlots; ++i) {
@@ -123,6 +125,29 @@ void build_tables(const rpw_config& c, PolarTables& t, std::vector<float>& bound
     const float sector_angle = 2.0f * M_PI / c.num_sectors;
     t.radius = c.filtering_radius;
     t.num_sectors = c.num_sectors;
+    // thresholds on s = x*x + y*y that are EQUIVALENT to the reference's comparisons of sqrtf(s):
+    // sqrtf is correctly rounded and monotone, so { s : sqrtf(s) >= e } is an upper set of floats.
+    auto min_s_with_sqrt_ge = [](float e) -> float {
+        if (!(e > 0.0f)) return 0.0f;                                   // sqrtf(s) >= e for every s >= 0
+        if (std::isinf(e)) return e;
+        float s = (float)((double)e * (double)e);
+        if (std::isinf(s)) s = std::numeric_limits<float>::max();
+        while (s > 0.0f && std::sqrt(std::nextafter(s, 0.0f)) >= e) s = std::nextafter(s, 0.0f);
+        while (!(std::sqrt(s) >= e)) { if (s == std::numeric_limits<float>::max()) return std::numeric_limits<float>::infinity(); s = std::nextafter(s, std::numeric_limits<float>::infinity()); }
+        return s;
+    };
+    auto min_s_with_sqrt_gt = [&](float r) -> float {
+        if (r < 0.0f) return 0.0f;                                      // nothing is <= a negative radius; s >= 0 always
+        if (std::isinf(r)) return r;
+        const float up = std::nextafter(r, std::numeric_limits<float>::infinity());
+        return min_s_with_sqrt_ge(up);
+    };
+    t.edges_monotone = 1;
+    for (int i = 0; i <= num_rings; ++i) {
+        t.ge[i] = min_s_with_sqrt_ge(t.edges[i]);
+        if (i && !(t.edges[i] >= t.edges[i - 1])) t.edges_monotone = 0;
+    }
+    t.gt_radius = min_s_with_sqrt_gt(c.filtering_radius);
     t.inv_sector = 1.0f / sector_angle;
     bounds.resize((size_t)c.num_sectors + 1);
     for (int k = 0; k <= c.num_sectors; ++k) bounds[k] = k * sector_angle;
@@ -143,7 +168,7 @@ rpw_status allocate(rpw_handle* h)
         RPW_HIP(h, hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
     }
     h->max_tiles = (uint32_t)(N / kTilePoints + F);
-    RPW_HIP(h, hipMalloc(&h->d_pid, N * sizeof(uint16_t)));
+    if (h->P + 3 <= 256) RPW_HIP(h, hipMalloc(&h->d_pid8, N)); else RPW_HIP(h, hipMalloc(&h->d_pid, N * sizeof(uint16_t)));
     RPW_HIP(h, hipMalloc(&h->d_hist, (size_t)h->max_tiles * h->PB * sizeof(uint32_t)));
     RPW_HIP(h, hipMalloc(&h->d_patch_begin, F * (size_t)(h->P + 1) * sizeof(uint32_t)));
     RPW_HIP(h, hipMalloc(&h->d_patches, F * (size_t)h->P * sizeof(PatchDesc)));
@@ -227,7 +252,7 @@ rpw_status run_batch(rpw_handle* h, const float* d_xyz, const uint32_t* frame_of
     p.cfg = h->cfg; p.tab = h->tab; p.bounds = h->d_bounds; p.S = h->S; p.P = h->P; p.PB = h->PB;
     p.n_frames = F; p.n_tiles = tiles; p.frame_off = h->d_offsets; p.tile_base = h->d_offsets + (F + 1);
     p.xyz = reinterpret_cast<const P3*>(d_xyz); p.labels = d_labels; p.residual = d_residual;
-    p.pid = h->d_pid; p.hist = h->d_hist; p.patch_begin = h->d_patch_begin; p.patches = h->d_patches;
+    p.pid = h->d_pid; p.pid8 = h->d_pid8; p.hist = h->d_hist; p.patch_begin = h->d_patch_begin; p.patches = h->d_patches;
     p.bucket_count = h->d_ctrl; p.bucket_list = h->d_bucket_list; p.list_stride = h->max_frames * (uint32_t)h->P;
     p.sx = h->d_sx; p.sy = h->d_sy; p.sz = h->d_sz; p.sidx = h->d_sidx; p.ax = h->d_ax; p.ay = h->d_ay; p.az = h->d_az;
     p.mask = h->d_mask; p.stats = h->d_stats;

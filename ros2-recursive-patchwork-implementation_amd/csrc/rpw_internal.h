@@ -40,7 +40,8 @@ struct DevParams {
     uint8_t*  labels;
     float*    residual;           // may be null
 
-    uint16_t* pid;                // [N] class per input point
+    uint16_t* pid;                // [N] class per input point (when P + 3 > 256)
+    uint8_t*  pid8;               // [N] same, one byte (when P + 3 <= 256); exactly one of the two is non-null
     uint32_t* hist;               // [n_tiles][PB]: counts, then (after scan) frame-relative offsets
     uint32_t* patch_begin;        // [F][P+1], frame-relative
     PatchDesc* patches;           // [F*P]

@@ -63,8 +63,10 @@ __global__ __launch_bounds__(kTileThreads) void classify_hist_kernel(DevParams p
 {
     extern __shared__ uint32_t lds_u32[];
     uint32_t* hist = lds_u32;                              // [PB]
+    float* bnd = reinterpret_cast<float*>(lds_u32 + p.PB); // [S+1] sector bounds
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int j = tid; j < p.PB; j += kTileThreads) hist[j] = 0;
+    for (int j = tid; j <= p.S; j += kTileThreads) bnd[j] = p.bounds[j];
     __syncthreads();
 
     const uint32_t tile = blockIdx.x;
@@ -74,15 +76,26 @@ __global__ __launch_bounds__(kTileThreads) void classify_hist_kernel(DevParams p
     const uint32_t t_local = tile - p.tile_base[f];
     const uint32_t wbase = t_local * kTilePoints + wave * kWavePoints;
 
-#pragma unroll 2
+    // all of the wave's loads first (8 x 12 B per lane in flight), then the arithmetic
+    P3 q[kTileItems];
+#pragma unroll
+    for (int r = 0; r < kTileItems; ++r) {
+        const uint32_t i = wbase + r * kWave + lane;
+        q[r].x = q[r].y = q[r].z = 1.0f;
+        if (i < nf) q[r] = p.xyz[fo + i];
+    }
+#pragma unroll
     for (int r = 0; r < kTileItems; ++r) {
         const uint32_t i = wbase + r * kWave + lane;
         const bool valid = i < nf;
-        int cls = 0;
+        bool unsure = false;
+        int cls = classify_point_fast(q[r].x, q[r].y, q[r].z, p.tab, bnd, unsure);
+        unsure = unsure && valid;
+        if (ballot64(unsure) != 0ull) {                    // rare: some lane sits within 1e-4 rad of a sector bound
+            if (unsure) cls = classify_point_exact(q[r].x, q[r].y, q[r].z, p.tab, bnd);
+        }
         if (valid) {
-            const P3 q = p.xyz[fo + i];
-            cls = classify_point(q.x, q.y, q.z, p.tab, p.bounds);
-            p.pid[fo + i] = (uint16_t)cls;
+            if (p.pid8) p.pid8[fo + i] = (uint8_t)cls; else p.pid[fo + i] = (uint16_t)cls;
         }
         unsigned long long rem = ballot64(valid);
         while (rem) {
@@ -124,40 +137,68 @@ __device__ __forceinline__ int size_bucket(uint32_t n)
     return b < kBuckets ? b : kBuckets - 1;
 }
 
-__global__ __launch_bounds__(kTileThreads) void scan_offsets_kernel(DevParams p)
+constexpr int kScanThreads = 1024;
+
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* red /*[16]*/, uint32_t& total)
 {
-    // One block per frame; thread c owns class c (patch ids, then the 3 special classes). Every load
-    // address is known up front, so the per-class walks over the tiles pipeline instead of paying one
-    // L2 round trip per step.
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t incl = wave_incl_scan(v);
+    if (lane == 63) red[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) { const uint32_t t = red[w]; if (w < wave) base += t; tot += t; }
+    total = tot;
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
+{
+    // One block per frame. Class c (patch ids, then the 3 special classes) is walked by `parts` threads,
+    // each over a contiguous range of tiles; every load address is known up front, so the walks
+    // pipeline instead of paying one L2 round trip per step.
     extern __shared__ uint32_t lds_u32[];
-    uint32_t* tot = lds_u32;                  // [PB] per-class totals, then exclusive prefix (patch_begin)
-    __shared__ uint32_t red[8];
+    const int C = p.P + 3;
+    int parts = kScanThreads / C; if (parts > 16) parts = 16; if (parts < 1) parts = 1;
+    uint32_t* tot = lds_u32;                  // [PB] per-class totals, then patch_begin
+    uint32_t* part = lds_u32 + p.PB;          // [parts][PB] partial totals, then exclusive prefix over parts
+    __shared__ uint32_t red[kScanThreads / 64];
     const int tid = threadIdx.x;
     const uint32_t f = blockIdx.x;
     const uint32_t t0 = p.tile_base[f];
     const uint32_t nt = p.tile_base[f + 1] - t0;
     const uint32_t fo = p.frame_off[f];
     const uint32_t nf = p.frame_off[f + 1] - fo;
-    const int C = p.P + 3;
     uint32_t* base = p.hist + (size_t)t0 * p.PB;
+    const uint32_t per = (nt + parts - 1) / parts;
 
-    for (int c = tid; c < C; c += kTileThreads) {
+    for (int w = tid; w < C * parts; w += kScanThreads) {
+        const int c = w % C, pt = w / C;
+        const uint32_t ta = pt * per, tb = ta + per < nt ? ta + per : nt;
         uint32_t acc = 0;
 #pragma unroll 8
-        for (uint32_t t = 0; t < nt; ++t) acc += base[(size_t)t * p.PB + c];
-        tot[c] = acc;
+        for (uint32_t t = ta; t < tb; ++t) acc += base[(size_t)t * p.PB + c];
+        part[pt * p.PB + c] = acc;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += kScanThreads) {
+        uint32_t s = 0;
+        for (int pt = 0; pt < parts; ++pt) { const uint32_t v = part[pt * p.PB + c]; part[pt * p.PB + c] = s; s += v; }
+        tot[c] = s;
     }
     __syncthreads();
     // zone < 3: the reference returns {{}, cleaned} before looking at any patch (recursive_patchwork.cpp:339-341)
     const bool zone_too_small = (nf - tot[p.P + 2] - tot[p.P + 1]) < 3u;
-    // exclusive prefix over the patch classes (chunks of 256), block-wide
+    const uint32_t n_dropped = tot[p.P + 2], n_outside = tot[p.P + 1];
+    // exclusive prefix over the patch classes, block-wide
     uint32_t running = 0, npatches = 0;
-    for (int c0 = 0; c0 < p.P; c0 += kTileThreads) {
+    for (int c0 = 0; c0 < p.P; c0 += kScanThreads) {
         const int c = c0 + tid;
         const uint32_t v = c < p.P ? tot[c] : 0u;
         uint32_t total, nz_total;
-        const uint32_t ex = block_excl_scan(v, red, total);
-        (void)block_excl_scan(v > 0 ? 1u : 0u, red, nz_total);
+        const uint32_t ex = block_excl_scan_1024(v, red, total);
+        (void)block_excl_scan_1024(v > 0 ? 1u : 0u, red, nz_total);
         if (c < p.P) {
             const uint32_t begin = running + ex;
             tot[c] = begin;
@@ -174,10 +215,12 @@ __global__ __launch_bounds__(kTileThreads) void scan_offsets_kernel(DevParams p)
     }
     __syncthreads();
     // running offsets per class over the tiles, in tile (= input) order
-    for (int c = tid; c < p.P; c += kTileThreads) {
-        uint32_t off = tot[c];
+    for (int w = tid; w < p.P * parts; w += kScanThreads) {
+        const int c = w % p.P, pt = w / p.P;
+        const uint32_t ta = pt * per, tb = ta + per < nt ? ta + per : nt;
+        uint32_t off = tot[c] + part[pt * p.PB + c];
 #pragma unroll 8
-        for (uint32_t t = 0; t < nt; ++t) {
+        for (uint32_t t = ta; t < tb; ++t) {
             uint32_t* cell = base + (size_t)t * p.PB + c;
             const uint32_t v = *cell;
             *cell = off;
@@ -188,8 +231,8 @@ __global__ __launch_bounds__(kTileThreads) void scan_offsets_kernel(DevParams p)
         p.patch_begin[(size_t)f * (p.P + 1) + p.P] = running;
         rpw_frame_stats st;
         st.n_in = nf;
-        st.n_clean = nf - tot[p.P + 2];
-        st.n_zone = st.n_clean - tot[p.P + 1];
+        st.n_clean = nf - n_dropped;
+        st.n_zone = st.n_clean - n_outside;
         st.n_ground = 0; st.n_patches = zone_too_small ? 0u : npatches; st.n_nodes = 0; st.n_splits = 0; st.max_depth = 0;
         st.total_iterations = 0;
         p.stats[f] = st;
@@ -220,18 +263,24 @@ __global__ __launch_bounds__(kTileThreads) void stable_scatter_kernel(DevParams 
     float px[kTileItems], py[kTileItems], pz[kTileItems];
     int cls[kTileItems];
     uint32_t loff[kTileItems];
+    // all loads first, then labels and ranks
+#pragma unroll
+    for (int r = 0; r < kTileItems; ++r) {
+        const uint32_t i = wbase + r * kWave + lane;
+        cls[r] = p.P; loff[r] = 0; px[r] = py[r] = pz[r] = 0.0f;
+        if (i < nf) {
+            const P3 q = p.xyz[fo + i];
+            px[r] = q.x; py[r] = q.y; pz[r] = q.z;
+            cls[r] = p.pid8 ? (int)p.pid8[fo + i] : (int)p.pid[fo + i];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < kTileItems; ++r) {
         const uint32_t i = wbase + r * kWave + lane;
         const bool valid = i < nf;
-        cls[r] = p.P;  loff[r] = 0; px[r] = py[r] = pz[r] = 0.0f;
         if (valid) {
-            const P3 q = p.xyz[fo + i];
-            px[r] = q.x; py[r] = q.y; pz[r] = q.z;
-            cls[r] = p.pid[fo + i];
             const int c = cls[r];
-            p.labels[fo + i] = (uint8_t)(c < p.P ? RPW_LABEL_NONGROUND
-                                       : (c == p.P ? RPW_LABEL_NONGROUND : (c == p.P + 1 ? RPW_LABEL_OUTSIDE : RPW_LABEL_DROPPED)));
+            p.labels[fo + i] = (uint8_t)(c <= p.P ? RPW_LABEL_NONGROUND : (c == p.P + 1 ? RPW_LABEL_OUTSIDE : RPW_LABEL_DROPPED));
             if (p.residual) p.residual[fo + i] = -1.0f;
         }
         const bool inpatch = valid && cls[r] < p.P;
@@ -873,12 +922,12 @@ __global__ void debug_eig3_kernel(const float* cov, float* nrm, uint32_t n)
 void launch_classify(const DevParams& p, hipStream_t s)
 {
     if (p.n_tiles == 0) return;
-    hipLaunchKernelGGL(classify_hist_kernel, dim3(p.n_tiles), dim3(kTileThreads), (size_t)p.PB * 4, s, p);
+    hipLaunchKernelGGL(classify_hist_kernel, dim3(p.n_tiles), dim3(kTileThreads), (size_t)(p.PB + p.S + 1) * 4, s, p);
 }
 void launch_scan(const DevParams& p, hipStream_t s)
 {
     if (p.n_frames == 0) return;
-    hipLaunchKernelGGL(scan_offsets_kernel, dim3(p.n_frames), dim3(kTileThreads), (size_t)p.PB * 4, s, p);
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(p.n_frames), dim3(kScanThreads), (size_t)p.PB * 17 * 4, s, p);
 }
 void launch_scatter(const DevParams& p, hipStream_t s)
 {

@@ -328,17 +328,91 @@ RPW_HD void smallest_eigenvector(float a00, float a10, float a11, float a20, flo
 
 // ---------------------------------------------------------------------------------------
 // polar classification (recursive_patchwork.cpp:315-378 per point)
+//
+// The reference compares d = sqrtf(x*x + y*y) with the ring edges and with the radius. sqrtf is
+// correctly rounded and monotone, so every such comparison is equivalent to a comparison of
+// s = x*x + y*y (same two products, same add) with a threshold the host derives exactly:
+//   d >= e   <=>   s >= ge[e]      with ge[e] = min { s : sqrtf(s) >= e }
+//   d <= R   <=>   s <  gt_radius  with gt_radius = min { s : sqrtf(s) > R }
+// For the sector, a cheap angle (error < 2e-5 rad) decides every point that is farther than 1e-4 rad
+// from a sector bound; the others (a few per 10^4) take the exact libm-model path.
 // ---------------------------------------------------------------------------------------
 struct PolarTables {
-    float edges[9];          // ring_edges[0..8]
+    float edges[9];          // ring_edges[0..8] (used by the literal fallback)
+    float ge[9];             // ge[i] = min { s : sqrtf(s) >= edges[i] }
+    float gt_radius;         // min { s : sqrtf(s) > filtering_radius }
     float radius;            // filtering_radius
     float inv_sector;        // 1 / sector_angle, only a search hint
     int   num_sectors;
-    // sector bounds bounds[k] = (float)k * sector_angle live in a separate array (device memory)
+    int   edges_monotone;    // edges non-decreasing (always, unless filtering_radius < 1)
+    // sector bounds bounds[k] = (float)k * sector_angle live in a separate array (device memory / LDS)
 };
 
-// returns ring*S + sector, or P + 0 (in zone, no patch), P + 1 (outside radius), P + 2 (non-finite)
-RPW_HD int classify_point(float x, float y, float z, const PolarTables& t, const float* __restrict__ bounds)
+RPW_HD float fast_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+// exact sector of angle a, or -1: the unique k with bounds[k] <= a < bounds[k+1]
+RPW_HD int sector_exact(float a, int S, float inv_sector, const float* __restrict__ bounds)
+{
+    int k = (int)(a * inv_sector);
+    if (k > S - 1) k = S - 1;
+    if (k < 0) k = 0;
+    while (k > 0 && a < bounds[k]) --k;
+    while (k < S && !(a < bounds[k + 1])) ++k;
+    if (k >= S || !(a >= bounds[k] && a < bounds[k + 1])) return -1;
+    return k;
+}
+
+// returns ring*S + sector, or P + 0 (in zone, no patch), P + 1 (outside radius), P + 2 (non-finite).
+// `uncertain` is set when the cheap angle cannot decide the sector; the caller then calls
+// classify_point_exact for that point. Straight-line code (selects, no branches).
+RPW_HD int classify_point_fast(float x, float y, float z, const PolarTables& t, const float* __restrict__ bounds, bool& uncertain)
+{
+    const int S = t.num_sectors;
+    const int P = 8 * S;
+    const bool fin = finite_(x) && finite_(y) && finite_(z);
+    const float s = x * x + y * y;
+    const bool inzone = s < t.gt_radius;
+    int ring;
+    if (t.edges_monotone) {
+        int c = 0;                      // ring = #{i : s >= ge[i]} - 1, valid if it is in 0..7
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c += (s >= t.ge[i]) ? 1 : 0;
+        ring = (c >= 1 && c <= 8) ? c - 1 : -1;
+    } else {
+        ring = -1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ring = (s >= t.ge[i] && s < t.ge[i + 1]) ? i : ring;
+    }
+    // cheap angle in [0, 2pi]: |error| < 2e-5 (degree-9 odd polynomial on [0,1], 1-ulp reciprocal)
+    const float ax = fabs_(x), ay = fabs_(y);
+    const bool steep = ay > ax;
+    const float mx = steep ? ay : ax, mn = steep ? ax : ay;
+    const float q = mn * fast_rcp(mx);
+    const float q2 = q * q;
+    // this path is approximate by design, so fused multiply-adds are welcome here
+    float p = q * __builtin_fmaf(q2, __builtin_fmaf(q2, __builtin_fmaf(q2, __builtin_fmaf(q2, 0.0208351f, -0.0851330f), 0.1801410f), -0.3302995f), 0.9998660f);
+    p = steep ? 1.57079637f - p : p;
+    p = x < 0.0f ? 3.14159274f - p : p;
+    p = y < 0.0f ? 6.28318548f - p : p;
+    int k = (int)(p * t.inv_sector);
+    k = k > S - 1 ? S - 1 : k;
+    k = k < 0 ? 0 : k;                   // also maps a NaN angle (x = y = 0 or non-finite input) to 0
+    const float eps = 1.0e-4f;
+    const bool sure = (p - bounds[k]) > eps && (bounds[k + 1] - p) > eps;
+    const bool inpatch = fin && inzone && ring >= 0;
+    uncertain = inpatch && !sure;
+    return !fin ? P + 2 : (!inzone ? P + 1 : ((ring < 0 || !sure) ? P : ring * S + k));
+}
+
+// the literal evaluation (libm-model angle), used for the few uncertain points and by the tests
+RPW_HD int classify_point_exact(float x, float y, float z, const PolarTables& t, const float* __restrict__ bounds)
 {
     const int S = t.num_sectors;
     const int P = 8 * S;
@@ -349,15 +423,8 @@ RPW_HD int classify_point(float x, float y, float z, const PolarTables& t, const
 #pragma unroll
     for (int i = 0; i < 8; ++i) if (d >= t.edges[i] && d < t.edges[i + 1]) ring = i;
     if (ring < 0) return P;
-    const float a = polar_angle(x, y);
-    // hint, then walk to the unique k with bounds[k] <= a < bounds[k+1] (bounds are non-decreasing)
-    int k = (int)(a * t.inv_sector);
-    if (k > S - 1) k = S - 1;
-    if (k < 0) k = 0;
-    while (k > 0 && a < bounds[k]) --k;
-    while (k < S && !(a < bounds[k + 1])) ++k;
-    if (k >= S || !(a >= bounds[k] && a < bounds[k + 1])) return P;
-    return ring * S + k;
+    const int k = sector_exact(polar_angle(x, y), S, t.inv_sector, bounds);
+    return k < 0 ? P : ring * S + k;
 }
 
 } // namespace rpw

@@ -150,3 +150,37 @@ def test_cpp_dropin_program(tmp_path):
                            "-L", pkg, "-lrecursive_patchwork", "-lrpw_hip", f"-Wl,-rpath,{pkg}"])
     out = subprocess.check_output([exe], text=True, timeout=300)
     assert "drop-in OK" in out
+
+
+def test_boundary_torture(engine_factory):
+    """Points on / one ulp around every ring edge and sector bound: the sqrt-free ring thresholds and the
+    fast sector test (exact libm-model fallback near a bound) must classify exactly like the oracle."""
+    rs = np.random.RandomState(5)
+    for kw in (dict(), dict(num_sectors=8, filtering_radius=50.0), dict(num_sectors=31, filtering_radius=80.0),
+               dict(num_sectors=40, filtering_radius=0.5), dict(num_sectors=3, filtering_radius=1.0)):
+        pc, oc = cfg_pair(**kw)
+        e, b = O.tables(oc)
+        pts = []
+        ups = lambda v, k: np.nextafter(np.float32(v), np.float32(np.inf if k > 0 else -np.inf)) if k else np.float32(v)
+        for edge in list(e) + [oc.filtering_radius]:
+            for k in (-2, -1, 0, 1, 2):
+                d = np.float32(edge)
+                for _ in range(abs(k)):
+                    d = ups(d, k)
+                for th in rs.uniform(0, 2 * np.pi, 6):
+                    pts.append((d * np.cos(th), d * np.sin(th), rs.normal(0, 0.05)))
+                pts += [(d, 0.0, 0.0), (0.0, d, 0.0), (-d, 0.0, 0.0), (0.0, -d, 0.0), (d, -0.0, 0.0)]
+        for ang in b:
+            for k in range(-3, 4):
+                a = np.float32(ang)
+                for _ in range(abs(k)):
+                    a = ups(a, k)
+                for r in rs.uniform(1.0, max(1.5, float(oc.filtering_radius)), 8):
+                    pts.append((r * np.cos(np.float64(a)), r * np.sin(np.float64(a)), rs.normal(0, 0.05)))
+        # a dense ring of ordinary points so that patches are non-trivial
+        base = W.c1_test_cloud(21, n=6000) * np.float32(min(1.0, float(oc.filtering_radius) / 50.0))
+        xyz = np.concatenate([np.array(pts, np.float32), base])
+        eng = engine_factory(pc, max_points=len(xyz), max_frames=1)
+        eng.set_trace(True, 1 << 16)
+        labels, res, st = eng.segment(xyz, want_residual=True)
+        assert_frame_parity(xyz, labels, res, st, eng.nodes(1 << 16), oc, tag=f"torture {kw}")
