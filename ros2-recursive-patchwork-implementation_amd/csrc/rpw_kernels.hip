@@ -137,7 +137,7 @@ __device__ __forceinline__ int size_bucket(uint32_t n)
     return b < kBuckets ? b : kBuckets - 1;
 }
 
-constexpr int kScanThreads = 1024;
+constexpr int kScanThreads = 256;     // small blocks: a 1024-thread block cannot be placed while patch_fit waves of other streams fill the CUs
 
 __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* red /*[16]*/, uint32_t& total)
 {
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kTileThreads) void stable_scatter_kernel(DevParams 
 // ------------------------------------------------------------------------------------------
 constexpr int kFitThreads = 128;
 constexpr int kLdw  = 68;              // ring row stride in floats: 64 + 4 keeps the 6 chain lanes on distinct banks
-constexpr int kRing = 4;               // ring slots (chunks of 64 points)
+constexpr int kRing = 8;               // ring slots of 64 addends; the producer writes at most 3 slots past the last rendezvous
 constexpr int kSlotFloats = 6 * kLdw;
 
 struct Raw { float x, y, z; uint32_t m; };
@@ -334,6 +334,7 @@ struct Raw { float x, y, z; uint32_t m; };
 struct FitShared {
     __attribute__((aligned(16))) float ring[kRing * kSlotFloats];
     float bc[16];                      // broadcast: chain sums, plane
+    uint32_t nslots;                   // chain_pass: number of compacted ring slots (kOpen while the producer is still working)
     uint32_t red[2][8];                // per-wave partial counts / flags
     float fred[2][8];                  // per-wave partial min / max
     uint32_t hist[256];
@@ -341,7 +342,9 @@ struct FitShared {
 };
 
 struct FitCtx {
-    const DevParams* p;
+    // raw pointers by value: taking the address of the kernel-argument struct would push it to scratch
+    const float *sx, *sy, *sz;
+    const uint8_t* mask;
     FitShared* sh;
     uint32_t base;        // absolute slot of the patch's first point
     int lane, wave, tid;
@@ -361,6 +364,9 @@ __device__ __forceinline__ unsigned long long stamp() { unsigned long long t; as
 
 // LDS-only rendezvous of the two waves: outstanding global loads (the producer's prefetch) stay in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// consumer side of the same rendezvous: it has written nothing, and its in-flight ds_reads target ring
+// slots the producer will not touch for two more steps, so it does not drain its LDS queue here
+__device__ __forceinline__ void lds_barrier_nowait() { asm volatile("s_barrier" ::: "memory"); }
 
 __device__ __forceinline__ Raw load_raw(const FitCtx& cx, uint32_t s, uint32_t n, uint32_t chunk)
 {
@@ -368,8 +374,8 @@ __device__ __forceinline__ Raw load_raw(const FitCtx& cx, uint32_t s, uint32_t n
     const uint32_t i = chunk * kWave + cx.lane;
     if (i < n) {
         const uint32_t g = cx.base + s + i;
-        r.x = cx.p->sx[g]; r.y = cx.p->sy[g]; r.z = cx.p->sz[g];
-        r.m = (uint32_t)cx.p->mask[g];                   // raw byte: nothing here may depend on a load's result
+        r.x = cx.sx[g]; r.y = cx.sy[g]; r.z = cx.sz[g];
+        r.m = (uint32_t)cx.mask[g];                   // raw byte: nothing here may depend on a load's result
     }
     return r;
 }
@@ -381,46 +387,79 @@ __device__ __forceinline__ Raw load_raw(const FitCtx& cx, uint32_t s, uint32_t n
 #endif
 
 // One chained pass over the node [s, s+n): K sequential sums, accumulator k in consumer lane k.
-// make(raw, i, out[K]) turns slot i (node-relative) into its K addends and may update the slot's mask
-// byte; post() runs once on the producer wave after its last chunk (to publish its own partials).
-// Result: sums[0..K-1] in every thread.
+// make(raw, i, ok, out[K]) -> bool: turns slot i (node-relative) into its K addends, may update the
+// slot's mask byte, and says whether the slot takes part at all. Slots that do not are SKIPPED: the
+// producer compacts the addends (ballot + mbcnt keep slot order), so the chain is as long as the number
+// of participating slots, not as the node. post() runs once on the producer wave after its last chunk
+// (to publish its own partials). Result: sums[0..K-1] in every thread.
+//
+// Rendezvous protocol (one LDS-only barrier per 64 addends): the consumer adds ring slot t between
+// barrier t and barrier t+1 and prefetches slot t+1; the producer calls barrier b only once slots
+// <= b+1 are complete (or the input is exhausted, after padding the last slot with -0.0f and
+// publishing the slot count). Both sides execute exactly nslots + 1 barriers.
+constexpr uint32_t kOpen = 0xffffffffu;
+
 template <int K, class Make, class Post>
 __device__ __forceinline__ void chain_pass(const FitCtx& cx, uint32_t s, uint32_t n, Make make, Post post, float* sums)
 {
     float* ring = cx.sh->ring;
+    volatile uint32_t* nslots_pub = &cx.sh->nslots;
     const uint32_t nch = (n + kWave - 1) / kWave;
     if (cx.wave == 1) {
         // ---------------- producer ----------------
-        auto fill = [&](uint32_t chunk, const Raw& r) {
-#if defined(RPW_EXP_NOFILL)     /* timing experiment only: results are wrong */
-            if (chunk > 1) return;
-#endif
-            float v[K];
-            const uint32_t i = chunk * kWave + cx.lane;
-            make(r, i, i < n, v);
-            float* slot = ring + (chunk & (kRing - 1)) * kSlotFloats + cx.lane;
+        uint32_t cursor = 0, next_barrier = 0;
+        if (cx.lane == 0) *nslots_pub = kOpen;
+        // Two chunks per call: their arithmetic is independent, so the compiler interleaves the two
+        // dependency chains (a dependent VALU op issues every ~8 cycles, an independent one every 4).
+        auto fill2 = [&](uint32_t chunk, const Raw& ra, const Raw& rb) __attribute__((always_inline)) {
+            float va[K], vb[K];
+            const uint32_t ia = chunk * kWave + cx.lane, ib = ia + kWave;
+            const bool ina = make(ra, ia, ia < n, va);
+            const bool inb = make(rb, ib, ib < n, vb);
+            const unsigned long long ma = ballot64(ina), mb = ballot64(inb);
+            const uint32_t ca = (uint32_t)__popcll(ma), cb = (uint32_t)__popcll(mb);
+            const uint32_t pa = cursor + (uint32_t)mbcnt64(ma);
+            const uint32_t pb = cursor + ca + (uint32_t)mbcnt64(mb);
+            // rendezvous that became due with the previous pair: made here, after this pair's arithmetic,
+            // when the previous pair's LDS writes have long landed (the wait inside is then free)
+            while ((cursor >> 6) >= next_barrier + 2) { RPW_T(tb0) lds_barrier(); RPW_T(tb1) RPW_ACC(t_bar, tb0, tb1) ++next_barrier; }
+            if (ina) {
+                float* dst = ring + ((pa >> 6) & (kRing - 1)) * kSlotFloats + (pa & 63u);
 #pragma unroll
-            for (int k = 0; k < K; ++k) slot[k * kLdw] = v[k];
+                for (int k = 0; k < K; ++k) dst[k * kLdw] = va[k];
+            }
+            if (inb) {
+                float* dst = ring + ((pb >> 6) & (kRing - 1)) * kSlotFloats + (pb & 63u);
+#pragma unroll
+                for (int k = 0; k < K; ++k) dst[k * kLdw] = vb[k];
+            }
+            cursor += ca + cb;
         };
-        RPW_T(tp0)
-        Raw r0 = load_raw(cx, s, n, 0), r1 = load_raw(cx, s, n, 1);
-        fill(0, r0); r0 = load_raw(cx, s, n, 2);
-        if (nch > 1) fill(1, r1);
-        r1 = load_raw(cx, s, n, 3);
-        lds_barrier();
-        RPW_T(tp1) RPW_ACC(t_pro, tp0, tp1)
-        // step t fills chunk t+2 from the register set loaded two steps earlier (no register rotation:
-        // a copy of a just-loaded register would force a wait on that load)
-        for (uint32_t t = 0; t < nch; t += 2) {
-            if (t + 2 < nch) fill(t + 2, r0);
-            r0 = load_raw(cx, s, n, t + 4);
-            { RPW_T(tb0) lds_barrier(); RPW_T(tb1) RPW_ACC(t_bar, tb0, tb1) }
-            if (t + 1 < nch) {
-                if (t + 3 < nch) fill(t + 3, r1);
-                r1 = load_raw(cx, s, n, t + 5);
-                { RPW_T(tb0) lds_barrier(); RPW_T(tb1) RPW_ACC(t_bar, tb0, tb1) }
+        RPW_T(tp1)
+        // four register sets, each reloaded right after use: a chunk's loads are issued four chunks
+        // of work ahead, and no just-loaded register is ever copied
+        Raw r0 = load_raw(cx, s, n, 0), r1 = load_raw(cx, s, n, 1), r2 = load_raw(cx, s, n, 2), r3 = load_raw(cx, s, n, 3);
+        for (uint32_t c = 0; c < nch; c += 4) {
+            fill2(c, r0, r1);
+            r0 = load_raw(cx, s, n, c + 4); r1 = load_raw(cx, s, n, c + 5);
+            if (c + 2 < nch) {
+                fill2(c + 2, r2, r3);
+                r2 = load_raw(cx, s, n, c + 6); r3 = load_raw(cx, s, n, c + 7);
             }
         }
+        while ((cursor >> 6) >= next_barrier + 2) { lds_barrier(); ++next_barrier; }
+        // pad the last slot with the additive identity, publish the slot count, finish the rendezvous
+        const uint32_t nslots = (cursor + 63u) >> 6;
+        {
+            const uint32_t pos = cursor + (uint32_t)cx.lane;
+            if (pos < (nslots << 6)) {
+                float* dst = ring + ((pos >> 6) & (kRing - 1)) * kSlotFloats + (pos & 63u);
+#pragma unroll
+                for (int k = 0; k < K; ++k) dst[k * kLdw] = -0.0f;
+            }
+        }
+        if (cx.lane == 0) *nslots_pub = nslots;
+        while (next_barrier < nslots + 1) { lds_barrier(); ++next_barrier; }
         RPW_T(tp2) RPW_ACC(t_loop, tp1, tp2)
         post();
     } else {
@@ -431,12 +470,16 @@ __device__ __forceinline__ void chain_pass(const FitCtx& cx, uint32_t s, uint32_
         const float* rowp = ring + row * kLdw;
         float acc = 0.0f;                                 // Zero(), then += in slot order
         RPW_T(tc0)
-        lds_barrier();
+        lds_barrier_nowait();                             // barrier 0
         RPW_T(tc1) RPW_ACC(t_pro, tc0, tc1)
+        uint32_t seen = *nslots_pub;                      // as of barrier 0: open => slots 0 and 1 exist
         float4 A[8], B[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const float4*>(rowp + 4 * q);
-        for (uint32_t t = 0; t < nch; ++t) {
+        bool exists = seen == kOpen || seen > 0u;
+        uint32_t t = 0;
+        while (exists) {
+            const uint32_t seen_t = *nslots_pub;          // as of barrier t; needed only after this step
             const float* cur = rowp + (t & (kRing - 1)) * kSlotFloats + 32;
             const float* nxt = rowp + ((t + 1) & (kRing - 1)) * kSlotFloats;
 #pragma unroll
@@ -444,12 +487,15 @@ __device__ __forceinline__ void chain_pass(const FitCtx& cx, uint32_t s, uint32_
 #pragma unroll
             for (int q = 0; q < 8; ++q) { A[q] = *reinterpret_cast<const float4*>(nxt + 4 * q); RPW_CHAIN4(acc, B[q]) __builtin_amdgcn_sched_barrier(0); }
             RPW_T(tb0)
-            lds_barrier();
+            lds_barrier_nowait();                         // barrier t + 1
             RPW_T(tb1) RPW_ACC(t_bar, tb0, tb1)
+            // if the producer was still open at barrier t it had completed slots <= t+1, so slot t+1 exists
+            ++t;
+            exists = seen_t == kOpen || t < seen_t;
         }
         RPW_T(tc2) RPW_ACC(t_loop, tc1, tc2)
 #if defined(RPW_STAMPS)
-        cx.n_chunks += nch; cx.n_pass += 1;
+        cx.n_chunks += t; cx.n_pass += 1;
 #endif
         if (cx.lane < K) cx.sh->bc[cx.lane] = acc;
     }
@@ -478,26 +524,27 @@ __device__ __forceinline__ void centroid_sums(const FitCtx& cx, uint32_t s, uint
 {
     chain_pass<3>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
         const bool in = ok && ((r.m >> bit) & 1u);
-        v[0] = in ? r.x : -0.0f; v[1] = in ? r.y : -0.0f; v[2] = in ? r.z : -0.0f;
+        v[0] = r.x; v[1] = r.y; v[2] = r.z;
+        return in;
     }, NoPost(), cs);
 }
 
 // given the centroid sums of the m >= 3 inliers (mask bit `bit`): covariance pass + eigenvector
 __device__ __forceinline__ void plane_from_sums(const FitCtx& cx, uint32_t s, uint32_t n, int bit, uint32_t m, const float* cs, PlaneD& pl)
 {
-    const float NZ = -0.0f;
     const float fm = (float)m;
     const float c0 = cs[0] / fm, c1 = cs[1] / fm, c2 = cs[2] / fm;
     float cv[6];
     chain_pass<6>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
         const bool in = ok && ((r.m >> bit) & 1u);
         const float dx = r.x - c0, dy = r.y - c1, dz = r.z - c2;
-        v[0] = in ? dx * dx : NZ;   // (0,0)
-        v[1] = in ? dy * dx : NZ;   // (1,0)
-        v[2] = in ? dy * dy : NZ;   // (1,1)
-        v[3] = in ? dz * dx : NZ;   // (2,0)
-        v[4] = in ? dz * dy : NZ;   // (2,1)
-        v[5] = in ? dz * dz : NZ;   // (2,2)
+        v[0] = dx * dx;   // (0,0)
+        v[1] = dy * dx;   // (1,0)
+        v[2] = dy * dy;   // (1,1)
+        v[3] = dz * dx;   // (2,0)
+        v[4] = dz * dy;   // (2,1)
+        v[5] = dz * dz;   // (2,2)
+        return in;
     }, NoPost(), cv);
     const float fm1 = (float)(m - 1);
     pl.cx = c0; pl.cy = c1; pl.cz = c2;
@@ -509,7 +556,8 @@ __device__ __forceinline__ float residual_masked(const FitCtx& cx, uint32_t s, u
     float r1[1];
     chain_pass<1>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
         const bool in = ok && ((r.m >> bit) & 1u);
-        v[0] = in ? plane_dist(r.x, r.y, r.z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz) : -0.0f;
+        v[0] = plane_dist(r.x, r.y, r.z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
+        return in;
     }, NoPost(), r1);
     return r1[0] / (float)m;
 }
@@ -528,9 +576,9 @@ __device__ __forceinline__ uint32_t float_key(float v) { const uint32_t u = __fl
 __device__ __forceinline__ float key_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 // exact order statistic: the value of rank k (0-based, ascending) among coordinate `axis` of the node
-__device__ float select_rank(const FitCtx& cx, uint32_t s, uint32_t n, int axis, uint32_t k)
+__device__ __forceinline__ float select_rank(const FitCtx& cx, uint32_t s, uint32_t n, int axis, uint32_t k)
 {
-    const float* src = (axis == 0 ? cx.p->sx : (axis == 1 ? cx.p->sy : cx.p->sz)) + cx.base + s;
+    const float* src = (axis == 0 ? cx.sx : (axis == 1 ? cx.sy : cx.sz)) + cx.base + s;
     uint32_t* hist = cx.sh->hist;
     uint32_t prefix = 0, pmask = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
@@ -568,9 +616,9 @@ __device__ float select_rank(const FitCtx& cx, uint32_t s, uint32_t n, int axis,
 // libstdc++ std::partial_sort(idx, idx+3, idx+n, z[a] < z[b]) restated for "the 3 lowest z":
 // __heap_select over a 3-element max-heap; returns the three selected slots (set semantics).
 // Every wave computes the same answer on its own (no cross-wave traffic).
-__device__ void three_lowest(const FitCtx& cx, uint32_t s, uint32_t n, uint32_t sel[3])
+__device__ __forceinline__ void three_lowest(const FitCtx& cx, uint32_t s, uint32_t n, uint32_t sel[3])
 {
-    const float* zs = cx.p->sz + cx.base + s;
+    const float* zs = cx.sz + cx.base + s;
     uint32_t h0 = 0, h1 = 1, h2 = 2;
     float z0 = zs[0], z1 = zs[1], z2 = zs[2];
     // __adjust_heap(first, 0, 3, value) + __push_heap, value = (vi, vz)
@@ -638,7 +686,7 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
     const PatchDesc pd = p.patches[linear];
     const uint32_t fo = p.frame_off[frame];
 
-    FitCtx cx; cx.p = &p; cx.sh = &sh; cx.base = pd.begin; cx.lane = lane; cx.wave = wave; cx.tid = tid;
+    FitCtx cx; cx.sx = p.sx; cx.sy = p.sy; cx.sz = p.sz; cx.mask = p.mask; cx.sh = &sh; cx.base = pd.begin; cx.lane = lane; cx.wave = wave; cx.tid = tid;
     const rpw_config& cfg = p.cfg;
     uint32_t* stk = sh.stk;
 
@@ -647,7 +695,8 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
     {
         float sum[1];
         chain_pass<1>(cx, 0, pd.n, [&](const Raw& r, uint32_t, bool ok, float* v) {
-            v[0] = ok ? sqrt_rn(r.x * r.x + r.y * r.y) : -0.0f;
+            v[0] = sqrt_rn(r.x * r.x + r.y * r.y);
+            return ok;
         }, NoPost(), sum);
         mean_dist = sum[0] / (float)pd.n;
     }
@@ -724,7 +773,8 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
                 const bool seed = ok && r.z < z_th;
                 if (ok) gm[i] = seed ? 1 : 0;
                 seeds += (uint32_t)__popcll(ballot64(seed));
-                v[0] = seed ? r.x : -0.0f; v[1] = seed ? r.y : -0.0f; v[2] = seed ? r.z : -0.0f;
+                v[0] = r.x; v[1] = r.y; v[2] = r.z;
+                return seed;
             }, [&]() { if (lane == 0) sh.red[1][0] = seeds; }, cs);
             count = sh.red[1][0];
             __syncthreads();
@@ -762,8 +812,11 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
                 differs_prev |= (nw != prev);
                 if (ok) gm[i] = (uint8_t)((nw ? 1u : 0u) | ((r.m & 0x7fu) << 1));
                 newcount += (uint32_t)__popcll(ballot64(nw));
-                v[0] = nw ? r.x : -0.0f; v[1] = nw ? r.y : -0.0f; v[2] = nw ? r.z : -0.0f;
+                // Compacted by the NEW mask. Row 3 carries |d| of the slots that are also in the OLD mask: it
+                // is the old-mask residual exactly when the two masks coincide, which is the only case it is used.
+                v[0] = r.x; v[1] = r.y; v[2] = r.z;
                 v[3] = old ? d : -0.0f;
+                return nw;
             }, [&]() {
                 const bool c = ballot64(changed) != 0ull, dp = ballot64(differs_prev) != 0ull;
                 if (lane == 0) { sh.red[1][0] = newcount; sh.red[1][1] = c ? 1u : 0u; sh.red[1][2] = dp ? 1u : 0u; }
@@ -786,8 +839,7 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
                 iters = cfg.max_iter;
                 if (remaining & 1) {                             // ends on the older mask: pl was fitted on it
                     final_bit = 1; count = oldcount;
-                    pl.residual = fs[3] / (float)count;
-                    have_plane = true; have_residual = true;
+                    have_plane = true;                           // its residual is recomputed below (row 3 is old AND new here)
                 }
                 break;
             }
@@ -808,13 +860,15 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
             // variance of x and y about the centroid of ALL node points, sequential sums
             float m2[2], v2[2];
             chain_pass<2>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
-                v[0] = ok ? r.x : -0.0f; v[1] = ok ? r.y : -0.0f;
+                v[0] = r.x; v[1] = r.y;
+                return ok;
             }, NoPost(), m2);
             const float fn = (float)n;
             const float mx = m2[0] / fn, my = m2[1] / fn;
             chain_pass<2>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
                 const float dx = r.x - mx, dy = r.y - my;
-                v[0] = ok ? dx * dx : -0.0f; v[1] = ok ? dy * dy : -0.0f;
+                v[0] = dx * dx; v[1] = dy * dy;
+                return ok;
             }, NoPost(), v2);
             const float var_x = v2[0] / fn, var_y = v2[1] / fn;
             const int axis = (var_x > var_y) ? 0 : 1;
