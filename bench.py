@@ -92,6 +92,20 @@ def cpu_baseline(frames, ocfg_kw, budget_s: float = 16.0):
     }
 
 
+def load_pmc_traffic(kernel: str, frames_per_launch: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, separate passes; tools/collect_traffic.sh). Only valid for the batch size it was taken at."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_bench.json")
+    try:
+        d = json.load(open(path))
+        if frames_per_launch != 256:
+            return None, None
+        v = d.get(kernel + "_kernel")
+        return (int(v["hbm_bytes_per_launch"]), "profiles/r01_pmc_traffic_bench.json") if v else (None, None)
+    except Exception:
+        return None, None
+
+
 def gather_counts(local_counts, world):
     """The path's only collective: all-gather of the per-frame result record (ground-point counts).
     RCCL on the GPU box (backend "nccl"), gloo in the CPU test."""
@@ -117,10 +131,10 @@ def max_over_ranks(elapsed: float, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=18)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step (one batch)")
-    ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (HIP streams, one engine each)")
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (one batch)")
+    ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (HIP streams, one engine each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-frame-latency", action="store_true",
                     help="also time batches of ONE frame (extra launches of the same kernels; off by default so that "
@@ -257,9 +271,13 @@ def main():
             avg_s = (kms[dom][0] / max(1, kms[dom][1])) * 1e-3
             bpp = BYTES_PER_POINT_FIT if dom == "patch_fit" else BYTES_PER_POINT_BIN
             ach = bpp * total_pts / avg_s / 1e9
+            traffic, traffic_src = load_pmc_traffic(dom, F)
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-                               "algorithmic_bytes_per_point": bpp}
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                               "traffic_source": traffic_src, "algorithmic_bytes_per_point": bpp,
+                               "algorithmic_bytes_per_launch": bpp * total_pts,
+                               "note": "patch_fit is bound by sequential binary32 add chains (8.2 cycles per dependent "
+                                       "v_add_f32), not by HBM; see DESIGN.md section 4"}
             bin_s = sum(kms[k][0] / max(1, kms[k][1]) for k in ("classify_hist", "scan_offsets", "stable_scatter")) * 1e-3
             achb = BYTES_PER_POINT_BIN * total_pts / bin_s / 1e9
             out["roofline_binning"] = {"kernels": "classify_hist+scan_offsets+stable_scatter", "bound": "hbm",
