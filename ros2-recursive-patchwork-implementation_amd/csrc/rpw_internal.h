@@ -33,6 +33,8 @@ struct DevParams {
 
     uint32_t        n_frames;
     uint32_t        n_tiles;      // over all frames
+    uint32_t        frame_first, frame_count;   // the frames this binning launch covers (a group of the batch)
+    uint32_t        tile_first, tile_count;     // and their tiles
     const uint32_t* frame_off;    // [F+1] device copy
     const uint32_t* tile_base;    // [F+1] first tile of each frame
 

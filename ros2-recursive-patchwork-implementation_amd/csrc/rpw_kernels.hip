@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kTileThreads) void classify_hist_kernel(DevParams p
     for (int j = tid; j <= p.S; j += kTileThreads) bnd[j] = p.bounds[j];
     __syncthreads();
 
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = blockIdx.x + p.tile_first;
     const uint32_t f = frame_of_tile(p.tile_base, p.n_frames, tile);
     const uint32_t fo = p.frame_off[f];
     const uint32_t nf = p.frame_off[f + 1] - fo;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
     uint32_t* part = lds_u32 + p.PB;          // [parts][PB] partial totals, then exclusive prefix over parts
     __shared__ uint32_t red[kScanThreads / 64];
     const int tid = threadIdx.x;
-    const uint32_t f = blockIdx.x;
+    const uint32_t f = blockIdx.x + p.frame_first;
     const uint32_t t0 = p.tile_base[f];
     const uint32_t nt = p.tile_base[f + 1] - t0;
     const uint32_t fo = p.frame_off[f];
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kTileThreads) void stable_scatter_kernel(DevParams 
     volatile uint32_t* wcnt = lds_u32;                    // [4][PB] per-wave running counts
     uint32_t* toff = lds_u32 + 4 * p.PB;                  // [PB] tile offsets (frame-relative)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = blockIdx.x + p.tile_first;
     for (int j = tid; j < 4 * p.PB; j += kTileThreads) wcnt[j] = 0;
     for (int j = tid; j < p.PB; j += kTileThreads) toff[j] = p.hist[(size_t)tile * p.PB + j];
     __syncthreads();
@@ -975,18 +975,18 @@ __global__ void debug_eig3_kernel(const float* cov, float* nrm, uint32_t n)
 // ------------------------------------------------------------------------------------------
 void launch_classify(const DevParams& p, hipStream_t s)
 {
-    if (p.n_tiles == 0) return;
-    hipLaunchKernelGGL(classify_hist_kernel, dim3(p.n_tiles), dim3(kTileThreads), (size_t)(p.PB + p.S + 1) * 4, s, p);
+    if (p.tile_count == 0) return;
+    hipLaunchKernelGGL(classify_hist_kernel, dim3(p.tile_count), dim3(kTileThreads), (size_t)(p.PB + p.S + 1) * 4, s, p);
 }
 void launch_scan(const DevParams& p, hipStream_t s)
 {
-    if (p.n_frames == 0) return;
-    hipLaunchKernelGGL(scan_offsets_kernel, dim3(p.n_frames), dim3(kScanThreads), (size_t)p.PB * 17 * 4, s, p);
+    if (p.frame_count == 0) return;
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(p.frame_count), dim3(kScanThreads), (size_t)p.PB * 17 * 4, s, p);
 }
 void launch_scatter(const DevParams& p, hipStream_t s)
 {
-    if (p.n_tiles == 0) return;
-    hipLaunchKernelGGL(stable_scatter_kernel, dim3(p.n_tiles), dim3(kTileThreads), (size_t)p.PB * 5 * 4, s, p);
+    if (p.tile_count == 0) return;
+    hipLaunchKernelGGL(stable_scatter_kernel, dim3(p.tile_count), dim3(kTileThreads), (size_t)p.PB * 5 * 4, s, p);
 }
 void launch_fit(const DevParams& p, hipStream_t s)
 {
