@@ -295,6 +295,7 @@ rpw_status run_batch(rpw_handle* h, const float* d_xyz, const uint32_t* frame_of
         timed(h, RPW_K_SCATTER, stream, [&] { launch_scatter(q, stream); });
     } else {
         const bool two_lanes = std::getenv("RPW_ONE_LANE") == nullptr;
+        if (two_lanes && !h->aux_stream) RPW_HIP(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
         hipStream_t aux = two_lanes ? h->aux_stream : stream;
         while (h->sync_events.size() < n_groups + 1) {
             hipEvent_t e = nullptr;
@@ -361,9 +362,9 @@ rpw_status rpw_create(const rpw_config* cfg, int device, uint32_t max_points, ui
     rpw_handle* h = new (std::nothrow) rpw_handle();
     if (!h) return fail(nullptr, RPW_ERR_INVALID, "out of host memory");
     h->cfg = c; h->device = device; h->max_points = max_points; h->max_frames = max_frames ? max_frames : 1;
-    e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete h; return RPW_ERR_HIP; }
+    // Streams are created lazily (own_stream by the host-pointer path, aux_stream by the grouped binning
+    // pipeline): ROCm multiplexes all streams of a process onto a few hardware queues, and an idle extra
+    // stream per handle is enough to make the caller's streams share queues and serialise.
     if (const char* gb = std::getenv("RPW_GROUP_MB")) h->group_bytes = (uint64_t)std::strtoull(gb, nullptr, 10) << 20;
     st = allocate(h);
     if (st != RPW_OK) { g_create_error = h->err; rpw_destroy(h); return st; }
@@ -435,6 +436,7 @@ rpw_status rpw_segment(rpw_handle* h, const float* xyz, uint32_t n, uint8_t* lab
     if (!h->d_in) RPW_HIP(h, hipMalloc(&h->d_in, N * 3 * sizeof(float)));
     if (!h->d_labels) RPW_HIP(h, hipMalloc(&h->d_labels, N));
     if (residual && !h->d_res) RPW_HIP(h, hipMalloc(&h->d_res, N * sizeof(float)));
+    if (!h->own_stream) RPW_HIP(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     hipStream_t s = h->own_stream;
     if (n) RPW_HIP(h, hipMemcpyAsync(h->d_in, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
     const uint32_t off[2] = {0, n};
@@ -506,8 +508,8 @@ rpw_status rpw_debug_angles(rpw_handle* h, const float* x, const float* y, float
     RPW_HIP(h, hipMalloc(&dx, bytes)); RPW_HIP(h, hipMalloc(&dy, bytes)); RPW_HIP(h, hipMalloc(&da, bytes));
     RPW_HIP(h, hipMemcpy(dx, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     RPW_HIP(h, hipMemcpy(dy, y, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-    launch_debug_angles(dx, dy, da, n, h->own_stream);
-    RPW_HIP(h, hipStreamSynchronize(h->own_stream));
+    launch_debug_angles(dx, dy, da, n, nullptr);
+    RPW_HIP(h, hipStreamSynchronize(nullptr));
     RPW_HIP(h, hipMemcpy(angle, da, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(da);
     return RPW_OK;
@@ -521,8 +523,8 @@ rpw_status rpw_debug_eig3(rpw_handle* h, const float* cov9, float* normal3, uint
     RPW_HIP(h, hipMalloc(&dc, (size_t)(n ? n : 1) * 9 * sizeof(float)));
     RPW_HIP(h, hipMalloc(&dn, (size_t)(n ? n : 1) * 3 * sizeof(float)));
     RPW_HIP(h, hipMemcpy(dc, cov9, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice));
-    launch_debug_eig3(dc, dn, n, h->own_stream);
-    RPW_HIP(h, hipStreamSynchronize(h->own_stream));
+    launch_debug_eig3(dc, dn, n, nullptr);
+    RPW_HIP(h, hipStreamSynchronize(nullptr));
     RPW_HIP(h, hipMemcpy(normal3, dn, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     (void)hipFree(dc); (void)hipFree(dn);
     return RPW_OK;
