@@ -7,12 +7,12 @@
 //                      patch-sorted SoA x,y,z + original index, input order kept inside a patch
 //   K4 patch_fit       fitPlaneAndSplit / fitPlanePCA / computeCentroid / computeCovariance /
 //                      Eigen solve / computePlaneDistances / mask compare / split + recursion
-//                      (recursive_patchwork.cpp:77-308), one wavefront per (frame, patch)
+//                      (recursive_patchwork.cpp:77-308), one two-wave workgroup per (frame, patch)
 //
 // Exactness: every sum the reference accumulates sequentially in binary32 (centroid,
 // covariance, residual, mean distance, variance) is accumulated here in the same order
-// by one lane per accumulator ("chain lanes"); the other 63 lanes of the wavefront only
-// prepare the addends. Built with -ffp-contract=off; divide and sqrt are correctly rounded.
+// by one lane per accumulator (the consumer wave); the producer wave only prepares the
+// addends. Built with -ffp-contract=off; divide and sqrt are correctly rounded.
 #include <hip/hip_runtime.h>
 #include "rpw_internal.h"
 
@@ -46,8 +46,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(v, o); if (l >= o) v += t; }
     return v;
 }
-__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 // ------------------------------------------------------------------------------------------
 // K1: classify + per-tile histogram
@@ -380,11 +378,7 @@ __device__ __forceinline__ Raw load_raw(const FitCtx& cx, uint32_t s, uint32_t n
     return r;
 }
 
-#if defined(RPW_EXP_NOADD)      /* timing experiment only: results are wrong */
-#define RPW_CHAIN4(ACC, Q) { ACC += (Q).x; asm volatile("" :: "v"((Q).y), "v"((Q).z), "v"((Q).w)); }
-#else
 #define RPW_CHAIN4(ACC, Q) { ACC += (Q).x; ACC += (Q).y; ACC += (Q).z; ACC += (Q).w; }
-#endif
 
 // One chained pass over the node [s, s+n): K sequential sums, accumulator k in consumer lane k.
 // make(raw, i, ok, out[K]) -> bool: turns slot i (node-relative) into its K addends, may update the
@@ -560,15 +554,6 @@ __device__ __forceinline__ float residual_masked(const FitCtx& cx, uint32_t s, u
         return in;
     }, NoPost(), r1);
     return r1[0] / (float)m;
-}
-
-// combine per-wave partial counters through LDS (both waves call; returns the sums to every thread)
-__device__ __forceinline__ void combine_u32(const FitCtx& cx, uint32_t* v, int cnt)
-{
-    if (cx.lane == 0) for (int i = 0; i < cnt; ++i) cx.sh->red[cx.wave][i] = v[i];
-    __syncthreads();
-    for (int i = 0; i < cnt; ++i) v[i] = cx.sh->red[0][i] + cx.sh->red[1][i];
-    __syncthreads();
 }
 
 // monotone key: ascending unsigned order == ascending float order
