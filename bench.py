@@ -278,9 +278,9 @@ def main():
                                "algorithmic_bytes_per_launch": bpp * total_pts,
                                "note": "patch_fit is bound by sequential binary32 add chains (8.2 cycles per dependent "
                                        "v_add_f32), not by HBM; see DESIGN.md section 4"}
-            bin_s = sum(kms[k][0] / max(1, kms[k][1]) for k in ("classify_hist", "scan_offsets", "stable_scatter")) * 1e-3
+            bin_s = sum(kms[k][0] / max(1, kms[k][1]) for k in ("bin_tile", "scan_offsets")) * 1e-3
             achb = BYTES_PER_POINT_BIN * total_pts / bin_s / 1e9
-            out["roofline_binning"] = {"kernels": "classify_hist+scan_offsets+stable_scatter", "bound": "hbm",
+            out["roofline_binning"] = {"kernels": "bin_tile+scan_offsets", "bound": "hbm",
                                        "achieved": round(achb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(achb / HBM_PEAK_GBS, 5), "traffic": None,
                                        "algorithmic_bytes_per_point": BYTES_PER_POINT_BIN}

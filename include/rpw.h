@@ -112,11 +112,10 @@ typedef struct rpw_handle rpw_handle;
 
 /* kernels timed by rpw_set_profiling / rpw_get_kernel_ms */
 enum {
-    RPW_K_CLASSIFY = 0,   /* classify + per-tile histogram         */
-    RPW_K_SCAN     = 1,   /* per-frame offsets                     */
-    RPW_K_SCATTER  = 2,   /* stable scatter to patch-sorted SoA    */
-    RPW_K_FIT      = 3,   /* per-patch recursive plane fit         */
-    RPW_K_COUNT    = 4
+    RPW_K_BIN   = 0,   /* classify + stable tile-local sort (binning pass, with RPW_K_SCAN) */
+    RPW_K_SCAN  = 1,   /* per-frame offsets                                                 */
+    RPW_K_FIT   = 2,   /* per-patch gather + recursive plane fit                            */
+    RPW_K_COUNT = 3
 };
 
 void        rpw_default_config(rpw_config* cfg);

@@ -25,8 +25,8 @@ ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("RPW_LIB", os.path.join(PKG_DIR, "librpw_hip.so"))
 
 LABEL_NONGROUND, LABEL_GROUND, LABEL_DROPPED, LABEL_OUTSIDE = 0, 1, 2, 3
-K_CLASSIFY, K_SCAN, K_SCATTER, K_FIT, K_COUNT = 0, 1, 2, 3, 4
-KERNEL_NAMES = ("classify_hist", "scan_offsets", "stable_scatter", "patch_fit")
+K_BIN, K_SCAN, K_FIT, K_COUNT = 0, 1, 2, 3
+KERNEL_NAMES = ("bin_tile", "scan_offsets", "patch_fit")
 
 
 class RpwError(RuntimeError):

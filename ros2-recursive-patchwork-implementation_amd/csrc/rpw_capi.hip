@@ -44,8 +44,6 @@ struct rpw_handle {
     bool stage_used[kStageSlots] = {};
     int stage_next = 0;
 
-    uint16_t* d_pid = nullptr;
-    uint8_t* d_pid8 = nullptr;
     uint32_t* d_hist = nullptr;
     uint32_t max_tiles = 0;
     uint32_t* d_patch_begin = nullptr;
@@ -53,6 +51,8 @@ struct rpw_handle {
     uint32_t* d_ctrl = nullptr;          // [kBuckets] bucket counts + [1] node count (+pad)
     uint32_t* d_bucket_list = nullptr;
     float *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr, *d_ax = nullptr, *d_ay = nullptr, *d_az = nullptr;
+    float *d_tx = nullptr, *d_ty = nullptr, *d_tz = nullptr;
+    uint32_t *d_tidx = nullptr, *d_tdir = nullptr;
     uint32_t* d_sidx = nullptr;
     uint8_t* d_mask = nullptr;
     rpw_frame_stats* d_stats = nullptr;
@@ -83,8 +83,8 @@ struct rpw_handle {
     int profiling = 0;
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> free_events;
-    double ms[RPW_K_COUNT] = {0, 0, 0, 0};
-    uint64_t launches[RPW_K_COUNT] = {0, 0, 0, 0};
+    double ms[RPW_K_COUNT] = {0, 0, 0};
+    uint64_t launches[RPW_K_COUNT] = {0, 0, 0};
 };
 
 namespace {
@@ -104,9 +104,9 @@ rpw_status fail(rpw_handle* h, rpw_status st, const char* fmt, ...)
 void free_device(rpw_handle* h)
 {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(h->d_bounds); F(h->d_offsets); F(h->d_pid); F(h->d_pid8); F(h->d_hist); F(h->d_patch_begin); F(h->d_patches);
+    F(h->d_bounds); F(h->d_offsets); F(h->d_hist); F(h->d_patch_begin); F(h->d_patches);
     F(h->d_ctrl); F(h->d_bucket_list); F(h->d_sx); F(h->d_sy); F(h->d_sz); F(h->d_ax); F(h->d_ay); F(h->d_az);
-    F(h->d_sidx); F(h->d_mask); F(h->d_stats); F(h->d_nodes); F(h->d_in); F(h->d_labels); F(h->d_res);
+    F(h->d_sidx); F(h->d_mask); F(h->d_tx); F(h->d_ty); F(h->d_tz); F(h->d_tidx); F(h->d_tdir); F(h->d_stats); F(h->d_nodes); F(h->d_in); F(h->d_labels); F(h->d_res);
     for (int i = 0; i < kStageSlots; ++i) {
         if (h->h_offsets[i]) { (void)hipHostFree(h->h_offsets[i]); h->h_offsets[i] = nullptr; }
         if (h->stage_ev[i]) { (void)hipEventDestroy(h->stage_ev[i]); h->stage_ev[i] = nullptr; }
@@ -176,7 +176,6 @@ rpw_status allocate(rpw_handle* h)
         RPW_HIP(h, hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
     }
     h->max_tiles = (uint32_t)(N / kTilePoints + F);
-    if (h->P + 3 <= 256) RPW_HIP(h, hipMalloc(&h->d_pid8, N)); else RPW_HIP(h, hipMalloc(&h->d_pid, N * sizeof(uint16_t)));
     RPW_HIP(h, hipMalloc(&h->d_hist, (size_t)h->max_tiles * h->PB * sizeof(uint32_t)));
     RPW_HIP(h, hipMalloc(&h->d_patch_begin, F * (size_t)(h->P + 1) * sizeof(uint32_t)));
     RPW_HIP(h, hipMalloc(&h->d_patches, F * (size_t)h->P * sizeof(PatchDesc)));
@@ -189,6 +188,14 @@ rpw_status allocate(rpw_handle* h)
     RPW_HIP(h, hipMalloc(&h->d_ay, N * sizeof(float)));
     RPW_HIP(h, hipMalloc(&h->d_az, N * sizeof(float)));
     RPW_HIP(h, hipMalloc(&h->d_sidx, N * sizeof(uint32_t)));
+    {   // tile-sorted arrays: a frame's region is rounded up to whole tiles
+        const size_t NT = (size_t)h->max_tiles * kTilePoints;
+        RPW_HIP(h, hipMalloc(&h->d_tx, NT * sizeof(float)));
+        RPW_HIP(h, hipMalloc(&h->d_ty, NT * sizeof(float)));
+        RPW_HIP(h, hipMalloc(&h->d_tz, NT * sizeof(float)));
+        RPW_HIP(h, hipMalloc(&h->d_tidx, NT * sizeof(uint32_t)));
+        RPW_HIP(h, hipMalloc(&h->d_tdir, (size_t)h->max_tiles * h->PB * sizeof(uint32_t)));
+    }
     RPW_HIP(h, hipMalloc(&h->d_mask, N));
     RPW_HIP(h, hipMalloc(&h->d_stats, F * sizeof(rpw_frame_stats)));
     if (h->trace && h->nodes_cap) RPW_HIP(h, hipMalloc(&h->d_nodes, (size_t)h->nodes_cap * sizeof(rpw_node)));
@@ -260,8 +267,9 @@ rpw_status run_batch(rpw_handle* h, const float* d_xyz, const uint32_t* frame_of
     p.cfg = h->cfg; p.tab = h->tab; p.bounds = h->d_bounds; p.S = h->S; p.P = h->P; p.PB = h->PB;
     p.n_frames = F; p.n_tiles = tiles; p.frame_first = 0; p.frame_count = F; p.tile_first = 0; p.tile_count = tiles; p.frame_off = h->d_offsets; p.tile_base = h->d_offsets + (F + 1);
     p.xyz = reinterpret_cast<const P3*>(d_xyz); p.labels = d_labels; p.residual = d_residual;
-    p.pid = h->d_pid; p.pid8 = h->d_pid8; p.hist = h->d_hist; p.patch_begin = h->d_patch_begin; p.patches = h->d_patches;
+    p.hist = h->d_hist; p.patch_begin = h->d_patch_begin; p.patches = h->d_patches;
     p.bucket_count = h->d_ctrl; p.bucket_list = h->d_bucket_list; p.list_stride = h->max_frames * (uint32_t)h->P;
+    p.tx = h->d_tx; p.ty = h->d_ty; p.tz = h->d_tz; p.tidx = h->d_tidx; p.tdir = h->d_tdir;
     p.sx = h->d_sx; p.sy = h->d_sy; p.sz = h->d_sz; p.sidx = h->d_sidx; p.ax = h->d_ax; p.ay = h->d_ay; p.az = h->d_az;
     p.mask = h->d_mask; p.stats = h->d_stats;
     p.trace = (h->trace && h->d_nodes) ? 1 : 0; p.nodes = h->d_nodes; p.node_count = h->d_ctrl + kBuckets; p.nodes_cap = h->nodes_cap;
@@ -290,9 +298,8 @@ rpw_status run_batch(rpw_handle* h, const float* d_xyz, const uint32_t* frame_of
     };
     if (n_groups <= 1) {
         const DevParams q = group_params(0);
-        timed(h, RPW_K_CLASSIFY, stream, [&] { launch_classify(q, stream); });
+        timed(h, RPW_K_BIN, stream, [&] { launch_bin(q, stream); });
         timed(h, RPW_K_SCAN, stream, [&] { launch_scan(q, stream); });
-        timed(h, RPW_K_SCATTER, stream, [&] { launch_scatter(q, stream); });
     } else {
         const bool two_lanes = std::getenv("RPW_ONE_LANE") == nullptr;
         if (two_lanes && !h->aux_stream) RPW_HIP(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
@@ -304,13 +311,12 @@ rpw_status run_batch(rpw_handle* h, const float* d_xyz, const uint32_t* frame_of
         }
         for (size_t g = 0; g < n_groups; ++g) {
             const DevParams q = group_params(g);
-            timed(h, RPW_K_CLASSIFY, stream, [&] { launch_classify(q, stream); });
+            timed(h, RPW_K_BIN, stream, [&] { launch_bin(q, stream); });
             if (two_lanes) {
                 RPW_HIP(h, hipEventRecord(h->sync_events[g], stream));
                 RPW_HIP(h, hipStreamWaitEvent(aux, h->sync_events[g], 0));
             }
             timed(h, RPW_K_SCAN, aux, [&] { launch_scan(q, aux); });
-            timed(h, RPW_K_SCATTER, aux, [&] { launch_scatter(q, aux); });
         }
         if (two_lanes) {
             RPW_HIP(h, hipEventRecord(h->sync_events[n_groups], aux));

@@ -42,8 +42,6 @@ struct DevParams {
     uint8_t*  labels;
     float*    residual;           // may be null
 
-    uint16_t* pid;                // [N] class per input point (when P + 3 > 256)
-    uint8_t*  pid8;               // [N] same, one byte (when P + 3 <= 256); exactly one of the two is non-null
     uint32_t* hist;               // [n_tiles][PB]: counts, then (after scan) frame-relative offsets
     uint32_t* patch_begin;        // [F][P+1], frame-relative
     PatchDesc* patches;           // [F*P]
@@ -51,7 +49,10 @@ struct DevParams {
     uint32_t* bucket_list;        // [kBuckets][list_stride]
     uint32_t  list_stride;
 
-    float *sx, *sy, *sz;          // patch-sorted SoA
+    float *tx, *ty, *tz;          // TILE-sorted SoA: inside every tile's 2048-slot region the points are grouped by patch
+    uint32_t* tidx;               // original index inside the frame, per tile-sorted slot
+    uint32_t* tdir;               // [n_tiles][PB] start of every class's run inside its tile
+    float *sx, *sy, *sz;          // patch-sorted SoA (assembled by patch_fit's gather)
     uint32_t* sidx;               // original index inside the frame, per slot (never permuted)
     float *ax, *ay, *az;          // scratch for the stable partition
     uint8_t* mask;                // per slot: bit0 = current inlier mask, bit1 = previous mask
@@ -63,9 +64,8 @@ struct DevParams {
     int       trace;
 };
 
-void launch_classify(const DevParams& p, hipStream_t s);
+void launch_bin(const DevParams& p, hipStream_t s);
 void launch_scan(const DevParams& p, hipStream_t s);
-void launch_scatter(const DevParams& p, hipStream_t s);
 void launch_fit(const DevParams& p, hipStream_t s);
 void launch_debug_angles(const float* x, const float* y, float* a, uint32_t n, hipStream_t s);
 void launch_debug_eig3(const float* cov9, float* normal3, uint32_t n, hipStream_t s);

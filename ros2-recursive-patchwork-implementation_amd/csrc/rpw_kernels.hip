@@ -1,11 +1,11 @@
 // rpw_kernels.hip -- hand-written gfx950 kernels of the Recursive Patchwork hot path.
 //
-//   K1 classify_hist   cleanPoints + computeDistances2D + filterPointsByRadius + computeAngles +
-//                      patch membership (recursive_patchwork.cpp:315-378), O(N) instead of O(P*N)
+//   K1 bin_tile        cleanPoints + computeDistances2D + filterPointsByRadius + computeAngles +
+//                      patch membership (recursive_patchwork.cpp:315-378), O(N) instead of O(P*N),
+//                      and a stable tile-local sort: points grouped by patch inside each 2048-point tile
 //   K2 scan_offsets    per-frame exclusive offsets (patch-major, then tile order = input order)
-//   K3 stable_scatter  the gather of recursive_patchwork.cpp:372-378 for all patches at once:
-//                      patch-sorted SoA x,y,z + original index, input order kept inside a patch
-//   K4 patch_fit       fitPlaneAndSplit / fitPlanePCA / computeCentroid / computeCovariance /
+//   K3 patch_fit       gather of the patch's runs (recursive_patchwork.cpp:372-378: patch_points in zone
+//                      order), then fitPlaneAndSplit / fitPlanePCA / computeCentroid / computeCovariance /
 //                      Eigen solve / computePlaneDistances / mask compare / split + recursion
 //                      (recursive_patchwork.cpp:77-308), one two-wave workgroup per (frame, patch)
 //
@@ -47,71 +47,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     return v;
 }
 
-// ------------------------------------------------------------------------------------------
-// K1: classify + per-tile histogram
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t frame_of_tile(const uint32_t* __restrict__ tile_base, uint32_t n_frames, uint32_t tile)
-{
-    uint32_t lo = 0, hi = n_frames;          // tile_base[lo] <= tile < tile_base[hi]
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (tile_base[mid] <= tile) lo = mid; else hi = mid; }
-    return lo;
-}
-
-__global__ __launch_bounds__(kTileThreads) void classify_hist_kernel(DevParams p)
-{
-    extern __shared__ uint32_t lds_u32[];
-    uint32_t* hist = lds_u32;                              // [PB]
-    float* bnd = reinterpret_cast<float*>(lds_u32 + p.PB); // [S+1] sector bounds
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int j = tid; j < p.PB; j += kTileThreads) hist[j] = 0;
-    for (int j = tid; j <= p.S; j += kTileThreads) bnd[j] = p.bounds[j];
-    __syncthreads();
-
-    const uint32_t tile = blockIdx.x + p.tile_first;
-    const uint32_t f = frame_of_tile(p.tile_base, p.n_frames, tile);
-    const uint32_t fo = p.frame_off[f];
-    const uint32_t nf = p.frame_off[f + 1] - fo;
-    const uint32_t t_local = tile - p.tile_base[f];
-    const uint32_t wbase = t_local * kTilePoints + wave * kWavePoints;
-
-    // all of the wave's loads first (8 x 12 B per lane in flight), then the arithmetic
-    P3 q[kTileItems];
-#pragma unroll
-    for (int r = 0; r < kTileItems; ++r) {
-        const uint32_t i = wbase + r * kWave + lane;
-        q[r].x = q[r].y = q[r].z = 1.0f;
-        if (i < nf) q[r] = p.xyz[fo + i];
-    }
-#pragma unroll
-    for (int r = 0; r < kTileItems; ++r) {
-        const uint32_t i = wbase + r * kWave + lane;
-        const bool valid = i < nf;
-        bool unsure = false;
-        int cls = classify_point_fast(q[r].x, q[r].y, q[r].z, p.tab, bnd, unsure);
-        unsure = unsure && valid;
-        if (ballot64(unsure) != 0ull) {                    // rare: some lane sits within 1e-4 rad of a sector bound
-            if (unsure) cls = classify_point_exact(q[r].x, q[r].y, q[r].z, p.tab, bnd);
-        }
-        if (valid) {
-            if (p.pid8) p.pid8[fo + i] = (uint8_t)cls; else p.pid[fo + i] = (uint16_t)cls;
-        }
-        unsigned long long rem = ballot64(valid);
-        while (rem) {
-            const int first = __ffsll((long long)rem) - 1;
-            const int c0 = __shfl(cls, first);
-            const unsigned long long m = ballot64(valid && cls == c0);
-            if (lane == first) atomicAdd(&hist[c0], (uint32_t)__popcll(m));
-            rem &= ~m;
-        }
-    }
-    __syncthreads();
-    uint32_t* out = p.hist + (size_t)tile * p.PB;
-    for (int j = tid; j < p.PB; j += kTileThreads) out[j] = hist[j];
-}
-
-// ------------------------------------------------------------------------------------------
-// K2: per-frame offsets. One 256-thread block per frame.
-// ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* red /*[5]*/, uint32_t& total)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -126,6 +61,119 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* red /*
     return base + incl - v;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// tile -> frame lookup
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t frame_of_tile(const uint32_t* __restrict__ tile_base, uint32_t n_frames, uint32_t tile)
+{
+    uint32_t lo = 0, hi = n_frames;          // tile_base[lo] <= tile < tile_base[hi]
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (tile_base[mid] <= tile) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: classify + TILE-LOCAL stable sort. One pass over the input: every tile of 2048 points is
+// read once (12 B/pt), classified, ranked (stable: wave-contiguous sub-tiles, ballot/mbcnt ranks, exclusive
+// prefix over the 4 waves and over the classes) and written back grouped by patch INSIDE the tile's own
+// 2048-slot region (16 B/pt), together with two small directories per tile: the run length of every class
+// (hist, turned into patch-relative destination offsets by K2) and the run start inside the tile (tdir).
+// The per-patch contiguous arrays are then assembled by patch_fit itself (its gather prologue), where
+// bandwidth is idle, so the binning pass touches HBM with 12 + 16 (+1 label) bytes per point.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
+{
+    extern __shared__ uint32_t lds_u32[];
+    volatile uint32_t* wcnt = lds_u32;                            // [4][PB] per-wave running counts, then wave offsets
+    uint32_t* tstart = lds_u32 + 4 * p.PB;                        // [PB] class totals, then run starts inside the tile
+    float* bnd = reinterpret_cast<float*>(lds_u32 + 5 * p.PB);    // [S+1] sector bounds
+    __shared__ uint32_t red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int j = tid; j < 4 * p.PB; j += kTileThreads) wcnt[j] = 0;
+    for (int j = tid; j <= p.S; j += kTileThreads) bnd[j] = p.bounds[j];
+    __syncthreads();
+
+    const uint32_t tile = blockIdx.x + p.tile_first;
+    const uint32_t f = frame_of_tile(p.tile_base, p.n_frames, tile);
+    const uint32_t fo = p.frame_off[f];
+    const uint32_t nf = p.frame_off[f + 1] - fo;
+    const uint32_t t_local = tile - p.tile_base[f];
+    const uint32_t wbase = t_local * kTilePoints + wave * kWavePoints;
+    volatile uint32_t* mycnt = wcnt + wave * p.PB;
+
+    // all of the wave's loads first (8 x 12 B per lane in flight), then the arithmetic
+    P3 q[kTileItems];
+#pragma unroll
+    for (int r = 0; r < kTileItems; ++r) {
+        const uint32_t i = wbase + r * kWave + lane;
+        q[r].x = q[r].y = q[r].z = 1.0f;
+        if (i < nf) q[r] = p.xyz[fo + i];
+    }
+    int cls[kTileItems];
+    uint32_t loff[kTileItems];
+#pragma unroll
+    for (int r = 0; r < kTileItems; ++r) {
+        const uint32_t i = wbase + r * kWave + lane;
+        const bool valid = i < nf;
+        bool unsure = false;
+        int c = classify_point_fast(q[r].x, q[r].y, q[r].z, p.tab, bnd, unsure);
+        unsure = unsure && valid;
+        if (ballot64(unsure) != 0ull) {                    // rare: some lane sits within 1e-4 rad of a sector bound
+            if (unsure) c = classify_point_exact(q[r].x, q[r].y, q[r].z, p.tab, bnd);
+        }
+        cls[r] = valid ? c : p.P;
+        loff[r] = 0;
+        if (valid) {
+            p.labels[fo + i] = (uint8_t)(c <= p.P ? RPW_LABEL_NONGROUND : (c == p.P + 1 ? RPW_LABEL_OUTSIDE : RPW_LABEL_DROPPED));
+            if (p.residual) p.residual[fo + i] = -1.0f;
+        }
+        // stable rank inside the wave's sub-tile: one step per distinct class of the row
+        unsigned long long rem = ballot64(valid);
+        while (rem) {
+            const int first = __ffsll((long long)rem) - 1;
+            const int c0 = __shfl(cls[r], first);
+            const unsigned long long m = ballot64(valid && cls[r] == c0);
+            const uint32_t old = mycnt[c0];
+            if (valid && cls[r] == c0) loff[r] = old + (uint32_t)mbcnt64(m);
+            if (lane == first) mycnt[c0] = old + (uint32_t)__popcll(m);
+            rem &= ~m;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < p.PB; c += kTileThreads) {              // exclusive prefix over the 4 waves, class total
+        uint32_t s = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const uint32_t t = wcnt[w * p.PB + c]; wcnt[w * p.PB + c] = s; s += t; }
+        tstart[c] = s;
+    }
+    __syncthreads();
+    uint32_t* hist_out = p.hist + (size_t)tile * p.PB;
+    uint32_t* tdir_out = p.tdir + (size_t)tile * p.PB;
+    uint32_t running = 0;
+    for (int c0 = 0; c0 < p.P; c0 += kTileThreads) {              // exclusive prefix over the patch classes
+        const int c = c0 + tid;
+        const uint32_t v = c < p.P ? tstart[c] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(v, red, total);
+        if (c < p.P) { hist_out[c] = v; tdir_out[c] = running + ex; tstart[c] = running + ex; }
+        running += total;
+    }
+    if (tid < 3) hist_out[p.P + tid] = tstart[p.P + tid];          // special classes: totals only
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kTileItems; ++r) {
+        const uint32_t i = wbase + r * kWave + lane;
+        if (i < nf && cls[r] < p.P) {
+            const uint32_t slot = fo + t_local * kTilePoints + tstart[cls[r]] + mycnt[cls[r]] + loff[r];
+            p.tx[slot] = q[r].x; p.ty[slot] = q[r].y; p.tz[slot] = q[r].z;
+            p.tidx[slot] = i;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: per-frame offsets. One 256-thread block per frame.
+// ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int size_bucket(uint32_t n)
 {
     // two buckets per power of two: 2*floor(log2 n) + next bit  (n >= 1)
@@ -238,81 +286,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
 }
 
 // ------------------------------------------------------------------------------------------
-// K3: stable scatter to patch-sorted SoA
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kTileThreads) void stable_scatter_kernel(DevParams p)
-{
-    extern __shared__ uint32_t lds_u32[];
-    volatile uint32_t* wcnt = lds_u32;                    // [4][PB] per-wave running counts
-    uint32_t* toff = lds_u32 + 4 * p.PB;                  // [PB] tile offsets (frame-relative)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x + p.tile_first;
-    for (int j = tid; j < 4 * p.PB; j += kTileThreads) wcnt[j] = 0;
-    for (int j = tid; j < p.PB; j += kTileThreads) toff[j] = p.hist[(size_t)tile * p.PB + j];
-    __syncthreads();
-
-    const uint32_t f = frame_of_tile(p.tile_base, p.n_frames, tile);
-    const uint32_t fo = p.frame_off[f];
-    const uint32_t nf = p.frame_off[f + 1] - fo;
-    const uint32_t t_local = tile - p.tile_base[f];
-    const uint32_t wbase = t_local * kTilePoints + wave * kWavePoints;
-    volatile uint32_t* mycnt = wcnt + wave * p.PB;
-
-    float px[kTileItems], py[kTileItems], pz[kTileItems];
-    int cls[kTileItems];
-    uint32_t loff[kTileItems];
-    // all loads first, then labels and ranks
-#pragma unroll
-    for (int r = 0; r < kTileItems; ++r) {
-        const uint32_t i = wbase + r * kWave + lane;
-        cls[r] = p.P; loff[r] = 0; px[r] = py[r] = pz[r] = 0.0f;
-        if (i < nf) {
-            const P3 q = p.xyz[fo + i];
-            px[r] = q.x; py[r] = q.y; pz[r] = q.z;
-            cls[r] = p.pid8 ? (int)p.pid8[fo + i] : (int)p.pid[fo + i];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < kTileItems; ++r) {
-        const uint32_t i = wbase + r * kWave + lane;
-        const bool valid = i < nf;
-        if (valid) {
-            const int c = cls[r];
-            p.labels[fo + i] = (uint8_t)(c <= p.P ? RPW_LABEL_NONGROUND : (c == p.P + 1 ? RPW_LABEL_OUTSIDE : RPW_LABEL_DROPPED));
-            if (p.residual) p.residual[fo + i] = -1.0f;
-        }
-        const bool inpatch = valid && cls[r] < p.P;
-        unsigned long long rem = ballot64(inpatch);
-        while (rem) {
-            const int first = __ffsll((long long)rem) - 1;
-            const int c0 = __shfl(cls[r], first);
-            const unsigned long long m = ballot64(inpatch && cls[r] == c0);
-            const uint32_t old = mycnt[c0];
-            if (inpatch && cls[r] == c0) loff[r] = old + (uint32_t)mbcnt64(m);
-            if (lane == first) mycnt[c0] = old + (uint32_t)__popcll(m);
-            rem &= ~m;
-        }
-    }
-    __syncthreads();
-    for (int j = tid; j < p.P; j += kTileThreads) {       // exclusive prefix over the 4 waves
-        uint32_t s = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { const uint32_t t = wcnt[w * p.PB + j]; wcnt[w * p.PB + j] = s; s += t; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kTileItems; ++r) {
-        const uint32_t i = wbase + r * kWave + lane;
-        if (i < nf && cls[r] < p.P) {
-            const uint32_t dest = fo + toff[cls[r]] + mycnt[cls[r]] + loff[r];
-            p.sx[dest] = px[r]; p.sy[dest] = py[r]; p.sz[dest] = pz[r];
-            p.sidx[dest] = i;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K4: per-patch recursive plane fit. One 2-wave workgroup per (frame, patch):
+// K3: per-patch gather + recursive plane fit. One 2-wave workgroup per (frame, patch):
 //   wave 0 = CONSUMER: runs nothing but the sequential binary32 add chains, one accumulator per
 //            lane, reading addends from an LDS ring (a dependent v_add_f32 chain retires one add
 //            per ~8 cycles on gfx950 and leaves every other issue slot empty);
@@ -323,6 +297,7 @@ __global__ __launch_bounds__(kTileThreads) void stable_scatter_kernel(DevParams 
 // order statistics, stable partition, labels).
 // ------------------------------------------------------------------------------------------
 constexpr int kFitThreads = 128;
+constexpr int kGatherTiles = 1024;     // frames up to 2.1 M points keep the gather's two directory columns in LDS
 constexpr int kLdw  = 68;              // ring row stride in floats: 64 + 4 keeps the 6 chain lanes on distinct banks
 constexpr int kRing = 8;               // ring slots of 64 addends; the producer writes at most 3 slots past the last rendezvous
 constexpr int kSlotFloats = 6 * kLdw;
@@ -337,6 +312,8 @@ struct FitShared {
     float fred[2][8];                  // per-wave partial min / max
     uint32_t hist[256];
     uint32_t stk[3 * kStackDepth];
+    uint32_t toff[kGatherTiles];       // gather prologue: this patch's destination offset per tile of the frame
+    uint32_t tsrc[kGatherTiles];       // gather prologue: this patch's source slot per tile of the frame
 };
 
 struct FitCtx {
@@ -675,6 +652,52 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
     const rpw_config& cfg = p.cfg;
     uint32_t* stk = sh.stk;
 
+    // ---- gather: assemble the patch's contiguous slots from its runs in the tile-sorted arrays ------------
+    // Run (tile t, this patch) lives at tile-slot tdir[t][patch] of tile t and goes to frame-relative slot
+    // hist[t][patch] (K2 turned the run lengths into destination offsets). Destination slot d belongs to the
+    // LAST tile whose offset is <= d (empty runs repeat an offset). Input order is kept: runs in tile order.
+    {
+        const uint32_t t0 = p.tile_base[frame];
+        const uint32_t nt = p.tile_base[frame + 1] - t0;
+        const bool in_lds = nt <= (uint32_t)kGatherTiles;
+        uint32_t* toff = sh.toff;                                       // destination offset of the run, per tile
+        uint32_t* tsrc = sh.tsrc;                                       // frame-relative source slot of the run, per tile
+        const uint32_t* goff = p.hist + (size_t)t0 * p.PB + patch;      // stride PB
+        const uint32_t* gdir = p.tdir + (size_t)t0 * p.PB + patch;      // stride PB
+        if (in_lds) for (uint32_t t = tid; t < nt; t += kFitThreads) {
+            toff[t] = goff[(size_t)t * p.PB];
+            tsrc[t] = t * kTilePoints + gdir[(size_t)t * p.PB];
+        }
+        __syncthreads();
+        const uint32_t rel0 = pd.begin - fo;
+        auto source_of = [&](uint32_t j) -> uint32_t {                  // tile-sorted slot that feeds patch slot j
+            const uint32_t d = rel0 + j;
+            uint32_t lo = 0, hi = nt;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t v = in_lds ? toff[mid] : goff[(size_t)mid * p.PB];
+                if (v <= d) lo = mid; else hi = mid;
+            }
+            const uint32_t o = in_lds ? toff[lo] : goff[(size_t)lo * p.PB];
+            const uint32_t sb = in_lds ? tsrc[lo] : lo * kTilePoints + gdir[(size_t)lo * p.PB];
+            return fo + sb + (d - o);
+        };
+        // four independent elements per thread and round: their loads are in flight together
+        for (uint32_t j0 = tid; j0 < pd.n; j0 += 4 * kFitThreads) {
+            uint32_t src[4]; float vx[4], vy[4], vz[4]; uint32_t vi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t j = j0 + u * kFitThreads; src[u] = j < pd.n ? source_of(j) : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (j0 + u * kFitThreads < pd.n) { vx[u] = p.tx[src[u]]; vy[u] = p.ty[src[u]]; vz[u] = p.tz[src[u]]; vi[u] = p.tidx[src[u]]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t j = j0 + u * kFitThreads;
+                if (j < pd.n) { const uint32_t dst = pd.begin + j; p.sx[dst] = vx[u]; p.sy[dst] = vy[u]; p.sz[dst] = vz[u]; p.sidx[dst] = vi[u]; }
+            }
+        }
+        __syncthreads();
+    }
+
     // ---- mean distance of the patch (recursive_patchwork.cpp:383-387): sequential sum of d ------
     float mean_dist;
     {
@@ -958,20 +981,15 @@ __global__ void debug_eig3_kernel(const float* cov, float* nrm, uint32_t n)
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-void launch_classify(const DevParams& p, hipStream_t s)
+void launch_bin(const DevParams& p, hipStream_t s)
 {
     if (p.tile_count == 0) return;
-    hipLaunchKernelGGL(classify_hist_kernel, dim3(p.tile_count), dim3(kTileThreads), (size_t)(p.PB + p.S + 1) * 4, s, p);
+    hipLaunchKernelGGL(bin_tile_kernel, dim3(p.tile_count), dim3(kTileThreads), (size_t)(5 * p.PB + p.S + 1) * 4, s, p);
 }
 void launch_scan(const DevParams& p, hipStream_t s)
 {
     if (p.frame_count == 0) return;
     hipLaunchKernelGGL(scan_offsets_kernel, dim3(p.frame_count), dim3(kScanThreads), (size_t)p.PB * 17 * 4, s, p);
-}
-void launch_scatter(const DevParams& p, hipStream_t s)
-{
-    if (p.tile_count == 0) return;
-    hipLaunchKernelGGL(stable_scatter_kernel, dim3(p.tile_count), dim3(kTileThreads), (size_t)p.PB * 5 * 4, s, p);
 }
 void launch_fit(const DevParams& p, hipStream_t s)
 {

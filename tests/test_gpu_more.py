@@ -184,3 +184,40 @@ def test_boundary_torture(engine_factory):
         eng.set_trace(True, 1 << 16)
         labels, res, st = eng.segment(xyz, want_residual=True)
         assert_frame_parity(xyz, labels, res, st, eng.nodes(1 << 16), oc, tag=f"torture {kw}")
+
+
+def test_randomised_configs_and_clouds(engine_factory):
+    """Seeded sweep over configurations and perturbed clouds: any divergence from the oracle in labels, stats,
+    residuals or the recursion tree fails. Covers odd sector counts, tiny / huge radii, every threshold knob,
+    shallow and deep recursion limits, both seed modes, NaN/inf injection, scaling, rotation, shuffled order."""
+    rs = np.random.RandomState(2024)
+    gens = [lambda s: W.c1_test_cloud(s, n=int(rs.randint(500, 30000))), lambda s: W.c2_hdl64(s)[:: int(rs.randint(1, 6))],
+            lambda s: W.c4_iac_fused(s, rays_per_sensor=20000)]
+    for it in range(36):
+        xyz = gens[it % 3](int(rs.randint(0, 1000))).copy()
+        if rs.rand() < 0.5:
+            xyz *= np.float32(rs.choice([0.25, 0.5, 2.0, 3.0]))
+        if rs.rand() < 0.5:
+            a = np.float32(rs.uniform(0, 6.28)); c, s = np.float32(np.cos(a)), np.float32(np.sin(a))
+            xyz = np.column_stack([xyz[:, 0] * c - xyz[:, 1] * s, xyz[:, 0] * s + xyz[:, 1] * c, xyz[:, 2]]).astype(np.float32)
+        if rs.rand() < 0.3:
+            xyz = xyz[rs.permutation(len(xyz))]
+        if rs.rand() < 0.4:
+            idx = rs.randint(0, len(xyz), 20)
+            xyz[idx, rs.randint(0, 3, 20)] = rs.choice([np.nan, np.inf, -np.inf], 20)
+        kw = dict(
+            num_sectors=int(rs.choice([1, 2, 3, 7, 10, 16, 31, 37, 64])),
+            filtering_radius=float(rs.choice([5.0, 30.0, 50.0, 150.0, 1000.0])),
+            max_iter=int(rs.choice([0, 1, 2, 5, 50, 100])),
+            max_split_depth=int(rs.choice([0, 1, 3, 10, 1000])),
+            th_dist=float(rs.choice([0.02, 0.1, 0.2, 0.5])),
+            th_seeds=float(rs.choice([0.05, 0.15, 0.5])),
+            sensor_height=float(rs.choice([-2.0, -1.5, 0.0, 1.2, 3.0])),
+            adaptive_seed_height=bool(rs.rand() < 0.7),
+        )
+        pc, oc = cfg_pair(**kw)
+        eng = engine_factory(pc, max_points=len(xyz), max_frames=1)
+        eng.set_trace(True, max(1 << 16, len(xyz)))
+        labels, res, st = eng.segment(xyz, want_residual=True)
+        assert_frame_parity(xyz, labels, res, st, eng.nodes(max(1 << 16, len(xyz))), oc, tag=f"case {it} {kw}")
+        eng.close()

@@ -18,6 +18,6 @@ for B in (1, 64, 256, 512):
     eng.set_profiling(True); eng.kernel_ms(reset=True)
     for _ in range(3): eng.segment_batch_device(d.data_ptr(), off, lab.data_ptr(), None, st)
     torch.cuda.synchronize()
-    k = {n: v[0] / v[1] for n, v in eng.kernel_ms().items()}
+    k = {n: v[0] / max(1, v[1]) for n, v in eng.kernel_ms().items()}
     print(B, "K4 ms %.3f  -> %.2f us/frame; chain-floor %.2f us/frame (8.2 cyc/add, 2 sweeps, 1024 WGs, 2.4 GHz)" % (k["patch_fit"], 1e3 * k["patch_fit"] / B, w.sum() * 2 * 8.2 / 2.4e3 / 1024))
     eng.close(); del d, lab

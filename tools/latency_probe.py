@@ -10,4 +10,4 @@ for _ in range(3): eng.segment_batch_device(d.data_ptr(), off, lab.data_ptr(), N
 torch.cuda.synchronize(); eng.set_profiling(True); eng.kernel_ms(reset=True)
 for _ in range(10): eng.segment_batch_device(d.data_ptr(), off, lab.data_ptr(), None, st)
 torch.cuda.synchronize()
-print(os.environ.get("RPW_LIB", "default"), {k: round(v[0] / v[1], 4) for k, v in eng.kernel_ms().items()})
+print(os.environ.get("RPW_LIB", "default"), {k: round(v[0] / max(1, v[1]), 4) for k, v in eng.kernel_ms().items()})
