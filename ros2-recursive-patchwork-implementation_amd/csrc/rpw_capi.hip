@@ -51,8 +51,8 @@ struct rpw_handle {
     uint32_t* d_ctrl = nullptr;          // [kBuckets] bucket counts + [1] node count (+pad)
     uint32_t* d_bucket_list = nullptr;
     float *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr, *d_ax = nullptr, *d_ay = nullptr, *d_az = nullptr;
-    float *d_tx = nullptr, *d_ty = nullptr, *d_tz = nullptr;
-    uint32_t *d_tidx = nullptr, *d_tdir = nullptr;
+    float4* d_tp = nullptr;
+    uint32_t* d_tdir = nullptr;
     uint32_t* d_sidx = nullptr;
     uint8_t* d_mask = nullptr;
     rpw_frame_stats* d_stats = nullptr;
@@ -106,7 +106,7 @@ void free_device(rpw_handle* h)
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(h->d_bounds); F(h->d_offsets); F(h->d_hist); F(h->d_patch_begin); F(h->d_patches);
     F(h->d_ctrl); F(h->d_bucket_list); F(h->d_sx); F(h->d_sy); F(h->d_sz); F(h->d_ax); F(h->d_ay); F(h->d_az);
-    F(h->d_sidx); F(h->d_mask); F(h->d_tx); F(h->d_ty); F(h->d_tz); F(h->d_tidx); F(h->d_tdir); F(h->d_stats); F(h->d_nodes); F(h->d_in); F(h->d_labels); F(h->d_res);
+    F(h->d_sidx); F(h->d_mask); F(h->d_tp); F(h->d_tdir); F(h->d_stats); F(h->d_nodes); F(h->d_in); F(h->d_labels); F(h->d_res);
     for (int i = 0; i < kStageSlots; ++i) {
         if (h->h_offsets[i]) { (void)hipHostFree(h->h_offsets[i]); h->h_offsets[i] = nullptr; }
         if (h->stage_ev[i]) { (void)hipEventDestroy(h->stage_ev[i]); h->stage_ev[i] = nullptr; }
@@ -188,12 +188,8 @@ rpw_status allocate(rpw_handle* h)
     RPW_HIP(h, hipMalloc(&h->d_ay, N * sizeof(float)));
     RPW_HIP(h, hipMalloc(&h->d_az, N * sizeof(float)));
     RPW_HIP(h, hipMalloc(&h->d_sidx, N * sizeof(uint32_t)));
-    {   // tile-sorted arrays: a frame's region is rounded up to whole tiles
-        const size_t NT = (size_t)h->max_tiles * kTilePoints;
-        RPW_HIP(h, hipMalloc(&h->d_tx, NT * sizeof(float)));
-        RPW_HIP(h, hipMalloc(&h->d_ty, NT * sizeof(float)));
-        RPW_HIP(h, hipMalloc(&h->d_tz, NT * sizeof(float)));
-        RPW_HIP(h, hipMalloc(&h->d_tidx, NT * sizeof(uint32_t)));
+    {   // tile-sorted records: slot < frame offset + frame size, so N records suffice
+        RPW_HIP(h, hipMalloc(&h->d_tp, N * sizeof(float4)));
         RPW_HIP(h, hipMalloc(&h->d_tdir, (size_t)h->max_tiles * h->PB * sizeof(uint32_t)));
     }
     RPW_HIP(h, hipMalloc(&h->d_mask, N));
@@ -269,7 +265,7 @@ rpw_status run_batch(rpw_handle* h, const float* d_xyz, const uint32_t* frame_of
     p.xyz = reinterpret_cast<const P3*>(d_xyz); p.labels = d_labels; p.residual = d_residual;
     p.hist = h->d_hist; p.patch_begin = h->d_patch_begin; p.patches = h->d_patches;
     p.bucket_count = h->d_ctrl; p.bucket_list = h->d_bucket_list; p.list_stride = h->max_frames * (uint32_t)h->P;
-    p.tx = h->d_tx; p.ty = h->d_ty; p.tz = h->d_tz; p.tidx = h->d_tidx; p.tdir = h->d_tdir;
+    p.tp = h->d_tp; p.tdir = h->d_tdir;
     p.sx = h->d_sx; p.sy = h->d_sy; p.sz = h->d_sz; p.sidx = h->d_sidx; p.ax = h->d_ax; p.ay = h->d_ay; p.az = h->d_az;
     p.mask = h->d_mask; p.stats = h->d_stats;
     p.trace = (h->trace && h->d_nodes) ? 1 : 0; p.nodes = h->d_nodes; p.node_count = h->d_ctrl + kBuckets; p.nodes_cap = h->nodes_cap;

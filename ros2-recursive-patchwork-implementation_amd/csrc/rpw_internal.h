@@ -49,8 +49,8 @@ struct DevParams {
     uint32_t* bucket_list;        // [kBuckets][list_stride]
     uint32_t  list_stride;
 
-    float *tx, *ty, *tz;          // TILE-sorted SoA: inside every tile's 2048-slot region the points are grouped by patch
-    uint32_t* tidx;               // original index inside the frame, per tile-sorted slot
+    float4* tp;                   // TILE-sorted records (x, y, z, original index as bits): inside every tile's
+                                  // 2048-slot region the points are grouped by patch, input order kept
     uint32_t* tdir;               // [n_tiles][PB] start of every class's run inside its tile
     float *sx, *sy, *sz;          // patch-sorted SoA (assembled by patch_fit's gather)
     uint32_t* sidx;               // original index inside the frame, per slot (never permuted)

@@ -165,8 +165,7 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
         const uint32_t i = wbase + r * kWave + lane;
         if (i < nf && cls[r] < p.P) {
             const uint32_t slot = fo + t_local * kTilePoints + tstart[cls[r]] + mycnt[cls[r]] + loff[r];
-            p.tx[slot] = q[r].x; p.ty[slot] = q[r].y; p.tz[slot] = q[r].z;
-            p.tidx[slot] = i;
+            p.tp[slot] = make_float4(q[r].x, q[r].y, q[r].z, __uint_as_float(i));     // one 16-byte store
         }
     }
 }
@@ -684,15 +683,15 @@ __global__ __launch_bounds__(kFitThreads) void patch_fit_kernel(DevParams p)
         };
         // four independent elements per thread and round: their loads are in flight together
         for (uint32_t j0 = tid; j0 < pd.n; j0 += 4 * kFitThreads) {
-            uint32_t src[4]; float vx[4], vy[4], vz[4]; uint32_t vi[4];
+            uint32_t src[4]; float4 v4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const uint32_t j = j0 + u * kFitThreads; src[u] = j < pd.n ? source_of(j) : 0u; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (j0 + u * kFitThreads < pd.n) { vx[u] = p.tx[src[u]]; vy[u] = p.ty[src[u]]; vz[u] = p.tz[src[u]]; vi[u] = p.tidx[src[u]]; }
+            for (int u = 0; u < 4; ++u) if (j0 + u * kFitThreads < pd.n) v4[u] = p.tp[src[u]];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t j = j0 + u * kFitThreads;
-                if (j < pd.n) { const uint32_t dst = pd.begin + j; p.sx[dst] = vx[u]; p.sy[dst] = vy[u]; p.sz[dst] = vz[u]; p.sidx[dst] = vi[u]; }
+                if (j < pd.n) { const uint32_t dst = pd.begin + j; p.sx[dst] = v4[u].x; p.sy[dst] = v4[u].y; p.sz[dst] = v4[u].z; p.sidx[dst] = __float_as_uint(v4[u].w); }
             }
         }
         __syncthreads();
