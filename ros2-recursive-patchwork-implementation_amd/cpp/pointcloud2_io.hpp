@@ -1,0 +1,58 @@
+// pointcloud2_io.hpp -- sensor_msgs/PointCloud2 wire format <-> std::vector<Point3D>, ROS-free.
+//
+// The reference node goes PointCloud2 -> pcl::fromROSMsg -> PointCloud<PointXYZ> -> vector<Point3D>
+// (reference src/recursive_patchwork_node.cpp:68-88) and back through pcl::toROSMsg (:110-157). These
+// helpers do the same conversions on the raw message bytes, so that neither PCL nor ROS headers are needed
+// to test them. Layout written: pcl::PointXYZ's (x, y, z float32 at 0/4/8, point_step 16), which is what
+// pcl::toROSMsg produces for that point type.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "recursive_patchwork.hpp"
+
+namespace recursive_patchwork {
+
+struct PointCloud2Layout {
+    uint32_t point_step = 16;   // bytes per point
+    uint32_t off_x = 0, off_y = 4, off_z = 8;   // FLOAT32 fields
+    bool bigendian = false;
+};
+
+// bytes -> points. `n` = width * height. Every point is kept (non-finite ones too: cleanPoints drops them on the path).
+inline std::vector<Point3D> pointsFromPointCloud2(const uint8_t* data, size_t n, const PointCloud2Layout& L)
+{
+    if (L.bigendian) throw std::runtime_error("big-endian PointCloud2 is not supported");
+    if (L.point_step < 12 || L.off_x + 4 > L.point_step || L.off_y + 4 > L.point_step || L.off_z + 4 > L.point_step)
+        throw std::runtime_error("PointCloud2: x/y/z FLOAT32 fields do not fit point_step");
+    std::vector<Point3D> pts(n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t* p = data + i * L.point_step;
+        std::memcpy(&pts[i].x, p + L.off_x, 4);
+        std::memcpy(&pts[i].y, p + L.off_y, 4);
+        std::memcpy(&pts[i].z, p + L.off_z, 4);
+    }
+    return pts;
+}
+
+// points -> bytes in the pcl::PointXYZ layout (padding word = 1.0f, as PCL leaves it)
+inline std::vector<uint8_t> pointCloud2FromPoints(const std::vector<Point3D>& pts, PointCloud2Layout* layout_out = nullptr)
+{
+    const PointCloud2Layout L;
+    std::vector<uint8_t> out(pts.size() * L.point_step);
+    const float one = 1.0f;
+    for (size_t i = 0; i < pts.size(); ++i) {
+        uint8_t* p = out.data() + i * L.point_step;
+        std::memcpy(p + 0, &pts[i].x, 4); std::memcpy(p + 4, &pts[i].y, 4); std::memcpy(p + 8, &pts[i].z, 4);
+        std::memcpy(p + 12, &one, 4);
+    }
+    if (layout_out) *layout_out = L;
+    return out;
+}
+
+} // namespace recursive_patchwork

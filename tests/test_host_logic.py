@@ -77,3 +77,12 @@ def test_multi_gpu_plumbing_gloo_world2():
     assert g0 == g1 and len(g0) == 4                         # every rank sees every frame's record
     assert t0 == t1 == 1.5                                   # MAX over ranks
     assert c0 != c1                                          # ranks process different frames
+
+
+def test_pointcloud2_io_cpp(tmp_path):
+    """The ROS-free PointCloud2 <-> Point3D conversions used by the ROS2 node source (cpp/ros2/)."""
+    import subprocess
+    exe = str(tmp_path / "pc2")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(rpw_amd.PKG_DIR, "cpp"),
+                           os.path.join(ROOT, "tests", "cpp", "test_pointcloud2_io.cpp"), "-o", exe])
+    assert "pointcloud2_io OK" in subprocess.check_output([exe], text=True)
