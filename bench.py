@@ -204,6 +204,7 @@ def main():
         if not np.array_equal(lab0, ref.labels):
             raise SystemExit("bench: HIP labels differ from the oracle on frame 0 -- refusing to report")
     gather_in.copy_(torch.from_numpy(st["n_ground"].astype(np.int32)))
+    chain_addends_per_batch = int(st["chain_addends"].astype(np.int64).sum())
 
     step_no[0] = 0
     if not args.no_profile_events:
@@ -288,6 +289,16 @@ def main():
                                "algorithmic_bytes_per_launch": bpp * total_pts,
                                "note": "patch_fit is bound by sequential binary32 add chains (8.2 cycles per dependent "
                                        "v_add_f32), not by HBM; see DESIGN.md section 4"}
+            # the bound that actually governs patch_fit: sequential binary32 adds. A dependent v_add_f32 retires every
+            # 3.4 ns (8.2 cycles, tools/microbench_chain.hip); a SIMD sustains two such chains at full rate, so the chip
+            # tops out at 256 CUs x 8 chains / 3.4 ns, whatever the lanes beside the chain lanes do.
+            chain_peak = 256 * 8 / 3.4e-9
+            chain_rate = chain_addends_per_batch * world * args.steps / elapsed
+            out["chain_roofline"] = {"kernel": "patch_fit", "bound": "dependent fp32 add latency",
+                                     "achieved": round(chain_rate / 1e9, 2), "peak": round(chain_peak / 1e9, 1),
+                                     "unit": "G sequential addends/s (per accumulator row)",
+                                     "frac": round(chain_rate / chain_peak, 4),
+                                     "addends_per_frame": chain_addends_per_batch // F}
             bin_s = sum(kms_solo[k][0] / max(1, kms_solo[k][1]) for k in ("bin_tile", "scan_offsets")) * 1e-3
             achb = BYTES_PER_POINT_BIN * total_pts / bin_s / 1e9
             out["roofline_binning"] = {"kernels": "bin_tile+scan_offsets", "bound": "hbm",

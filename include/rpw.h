@@ -87,6 +87,8 @@ typedef struct rpw_frame_stats {
     uint32_t n_splits;
     uint32_t max_depth;
     uint64_t total_iterations;   /* plane refits inside the loops, summed over nodes  */
+    uint64_t chain_addends;      /* elements summed sequentially per accumulator row, over all chained sweeps
+                                    (the work the add-dependency chains had to do; not defined by the reference) */
 } rpw_frame_stats;
 
 /* Recursion-tree trace record (optional output, see rpw_set_trace). */

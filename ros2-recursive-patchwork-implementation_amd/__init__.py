@@ -46,7 +46,7 @@ class CFrameStats(C.Structure):
     _fields_ = [
         ("n_in", C.c_uint32), ("n_clean", C.c_uint32), ("n_zone", C.c_uint32), ("n_ground", C.c_uint32),
         ("n_patches", C.c_uint32), ("n_nodes", C.c_uint32), ("n_splits", C.c_uint32),
-        ("max_depth", C.c_uint32), ("total_iterations", C.c_uint64),
+        ("max_depth", C.c_uint32), ("total_iterations", C.c_uint64), ("chain_addends", C.c_uint64),
     ]
 
 
@@ -57,7 +57,7 @@ NODE_DTYPE = np.dtype([
 ])
 STATS_DTYPE = np.dtype([
     ("n_in", "<u4"), ("n_clean", "<u4"), ("n_zone", "<u4"), ("n_ground", "<u4"), ("n_patches", "<u4"),
-    ("n_nodes", "<u4"), ("n_splits", "<u4"), ("max_depth", "<u4"), ("total_iterations", "<u8"),
+    ("n_nodes", "<u4"), ("n_splits", "<u4"), ("max_depth", "<u4"), ("total_iterations", "<u8"), ("chain_addends", "<u8"),
 ])
 assert STATS_DTYPE.itemsize == C.sizeof(CFrameStats)
 

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
         st.n_clean = nf - n_dropped;
         st.n_zone = st.n_clean - n_outside;
         st.n_ground = 0; st.n_patches = zone_too_small ? 0u : npatches; st.n_nodes = 0; st.n_splits = 0; st.max_depth = 0;
-        st.total_iterations = 0;
+        st.total_iterations = 0; st.chain_addends = 0;
         p.stats[f] = st;
     }
 }
@@ -306,6 +306,7 @@ struct Raw { float x, y, z; uint32_t m; };
 struct FitShared {
     __attribute__((aligned(16))) float ring[kRing * kSlotFloats];
     float bc[16];                      // broadcast: chain sums, plane
+    unsigned long long chain_addends;  // addends handed to the chains so far (per accumulator row); producer lane 0 only
     uint32_t nslots;                   // chain_pass: number of compacted ring slots (kOpen while the producer is still working)
     uint32_t red[2][8];                // per-wave partial counts / flags
     float fred[2][8];                  // per-wave partial min / max
@@ -429,6 +430,7 @@ __device__ __forceinline__ void chain_pass(const FitCtx& cx, uint32_t s, uint32_
             }
         }
         if (cx.lane == 0) *nslots_pub = nslots;
+        if (cx.lane == 0) cx.sh->chain_addends += cursor;      // statistics only (LDS, no register held for it)
         while (next_barrier < nslots + 1) { lds_barrier(); ++next_barrier; }
         RPW_T(tp2) RPW_ACC(t_loop, tp1, tp2)
         post();
@@ -649,6 +651,7 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
     const PatchDesc pd = p.patches[linear];
     const uint32_t fo = p.frame_off[frame];
 
+    if (wave == 1 && lane == 0) sh.chain_addends = 0ull;
     FitCtx cx; cx.sx = p.sx; cx.sy = p.sy; cx.sz = p.sz; cx.mask = p.mask; cx.sh = &sh; cx.base = pd.begin; cx.lane = lane; cx.wave = wave; cx.tid = tid;
     const rpw_config& cfg = p.cfg;
     uint32_t* stk = sh.stk;
@@ -950,6 +953,7 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
         d[0] = t_kernel1 - t_kernel0; d[1] = cx.t_loop; d[2] = cx.t_bar; d[3] = cx.n_chunks; d[4] = cx.n_pass; d[5] = cx.t_pro; d[6] = cx.t_epi; d[7] = pd.n;
     }
 #endif
+    if (wave == 1 && lane == 0) atomicAdd((unsigned long long*)&p.stats[frame].chain_addends, sh.chain_addends);
     if (tid == 0) {
         rpw_frame_stats* st = p.stats + frame;
         atomicAdd(&st->n_ground, pa.ground);
