@@ -141,6 +141,14 @@ const char* rpw_last_error(const rpw_handle* h);   /* h may be NULL: message of 
 rpw_status  rpw_segment(rpw_handle* h, const float* xyz, uint32_t n, uint8_t* labels,
                         float* residual, rpw_frame_stats* stats);
 
+/* Same call on the bytes of a sensor_msgs/PointCloud2 message (what the reference node receives,
+ * reference src/recursive_patchwork_node.cpp:61-88): n = width * height records of point_step bytes with
+ * little-endian FLOAT32 x / y / z fields at byte offsets off_x / off_y / off_z (4-byte aligned). The records
+ * are copied to the device as they are and read in place by the binning kernel: no host-side repacking. */
+rpw_status  rpw_segment_pointcloud2(rpw_handle* h, const uint8_t* data, uint32_t n, uint32_t point_step,
+                                    uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                                    uint8_t* labels, float* residual, rpw_frame_stats* stats);
+
 /* Device-resident batch, asynchronous on `stream` (a hipStream_t, NULL = default stream).
  *   d_xyz          device pointer, frames concatenated, AoS
  *   frame_offsets  HOST array of n_frames + 1 point offsets (frame f = [off[f], off[f+1]))

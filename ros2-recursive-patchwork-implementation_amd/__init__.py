@@ -121,6 +121,8 @@ def load_library():
     L.rpw_get_config.restype = i32
     L.rpw_segment.argtypes = [vp, vp, u32, vp, vp, C.POINTER(CFrameStats)]
     L.rpw_segment.restype = i32
+    L.rpw_segment_pointcloud2.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, vp, C.POINTER(CFrameStats)]
+    L.rpw_segment_pointcloud2.restype = i32
     L.rpw_segment_batch_device.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     L.rpw_segment_batch_device.restype = i32
     L.rpw_get_batch_stats.argtypes = [vp, vp, u32]
@@ -145,7 +147,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = (
     "rpw_default_config", "rpw_abi_version", "rpw_create", "rpw_destroy", "rpw_set_config", "rpw_get_config",
-    "rpw_last_error", "rpw_segment", "rpw_segment_batch_device", "rpw_get_batch_stats", "rpw_set_trace",
+    "rpw_last_error", "rpw_segment", "rpw_segment_pointcloud2", "rpw_segment_batch_device", "rpw_get_batch_stats", "rpw_set_trace",
     "rpw_get_nodes", "rpw_set_profiling", "rpw_get_kernel_ms", "rpw_debug_angles", "rpw_debug_eig3",
     "rpw_debug_angles_host",
 )
@@ -208,6 +210,18 @@ class Engine:
         st = CFrameStats()
         self._check(self._L.rpw_segment(self._h, xyz.ctypes.data, n, labels.ctypes.data,
                                         res.ctypes.data if res is not None else None, C.byref(st)))
+        return labels, res, {k: getattr(st, k) for k, _ in CFrameStats._fields_}
+
+    def segment_pointcloud2(self, data: np.ndarray, n: int, point_step: int, off_x: int, off_y: int, off_z: int,
+                            want_residual: bool = False):
+        """One frame given as PointCloud2 message bytes (uint8 array of n * point_step bytes)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        labels = np.empty(n, np.uint8)
+        res = np.empty(n, np.float32) if want_residual else None
+        st = CFrameStats()
+        self._check(self._L.rpw_segment_pointcloud2(self._h, data.ctypes.data, n, point_step, off_x, off_y, off_z,
+                                                    labels.ctypes.data, res.ctypes.data if res is not None else None,
+                                                    C.byref(st)))
         return labels, res, {k: getattr(st, k) for k, _ in CFrameStats._fields_}
 
     def segment_batch_device(self, d_xyz_ptr: int, frame_offsets: np.ndarray, d_labels_ptr: int,

@@ -3,6 +3,7 @@
 #include "recursive_patchwork.hpp"
 
 #include <cmath>
+#include <cstring>
 #include <iostream>
 #include <stdexcept>
 
@@ -84,6 +85,35 @@ std::vector<unsigned char> RecursivePatchwork::segment(const std::vector<Point3D
     if (rc != RPW_OK) throw std::runtime_error(std::string("RecursivePatchwork: rpw_segment failed: ") + rpw_last_error(handle_));
     n_zone_last_ = st.n_zone;
     return labels;
+}
+
+std::pair<std::vector<Point3D>, std::vector<Point3D>>
+RecursivePatchwork::filterGroundPointCloud2(const unsigned char* data, size_t n, unsigned point_step,
+                                            unsigned off_x, unsigned off_y, unsigned off_z)
+{
+    ensure(n);
+    std::vector<unsigned char> labels(n);
+    rpw_frame_stats st;
+    const rpw_status rc = rpw_segment_pointcloud2(handle_, data, (uint32_t)n, point_step, off_x, off_y, off_z,
+                                                  labels.data(), nullptr, &st);
+    if (rc != RPW_OK) throw std::runtime_error(std::string("RecursivePatchwork: rpw_segment_pointcloud2 failed: ") + rpw_last_error(handle_));
+    n_zone_last_ = st.n_zone;
+    auto point = [&](size_t i) {
+        Point3D p; const unsigned char* r = data + i * point_step;
+        std::memcpy(&p.x, r + off_x, 4); std::memcpy(&p.y, r + off_y, 4); std::memcpy(&p.z, r + off_z, 4);
+        return p;
+    };
+    std::vector<Point3D> ground, non_ground;
+    if (st.n_zone < 3) {
+        for (size_t i = 0; i < n; ++i) if (labels[i] != RPW_LABEL_DROPPED) non_ground.push_back(point(i));
+        return {ground, non_ground};
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (labels[i] == RPW_LABEL_GROUND) ground.push_back(point(i));
+        else if (labels[i] == RPW_LABEL_NONGROUND) non_ground.push_back(point(i));
+    }
+    for (size_t i = 0; i < n; ++i) if (labels[i] == RPW_LABEL_OUTSIDE) non_ground.push_back(point(i));
+    return {ground, non_ground};
 }
 
 std::pair<std::vector<Point3D>, std::vector<Point3D>>

@@ -52,6 +52,13 @@ public:
     // optionally, per-point residuals. BASELINE.json calls this segment(PointCloud&).
     std::vector<unsigned char> segment(const std::vector<Point3D>& points, std::vector<float>* residuals = nullptr);
 
+    // Build-side addition for the ROS2 node: the same call on the bytes of a sensor_msgs/PointCloud2 message
+    // (n records of point_step bytes, FLOAT32 x/y/z at the given byte offsets). The records go to the GPU as
+    // they are; the returned pair is rebuilt from the labels in the reference's order.
+    std::pair<std::vector<Point3D>, std::vector<Point3D>>
+    filterGroundPointCloud2(const unsigned char* data, size_t n, unsigned point_step,
+                            unsigned off_x, unsigned off_y, unsigned off_z);
+
     std::vector<Point3D> cleanPoints(const std::vector<Point3D>& points);
 
     void setConfig(const PatchworkConfig& config);

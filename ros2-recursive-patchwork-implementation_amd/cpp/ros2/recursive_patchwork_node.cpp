@@ -89,8 +89,11 @@ private:
             PointCloud2Layout L;
             if (!findLayout(msg, L)) { RCLCPP_ERROR(get_logger(), "PointCloud2 without FLOAT32 x/y/z fields"); return; }
             const size_t n = static_cast<size_t>(msg.width) * msg.height;
-            const std::vector<Point3D> points = pointsFromPointCloud2(msg.data.data(), n, L);
-            auto [ground, obstacles] = processor_->filterGroundPoints(points);
+            if (L.bigendian || (L.point_step & 3u) || (L.off_x & 3u) || (L.off_y & 3u) || (L.off_z & 3u)) {
+                RCLCPP_ERROR(get_logger(), "unsupported PointCloud2 layout"); return;
+            }
+            // the message bytes go to the GPU as they are (no PCL hop, no host repacking)
+            auto [ground, obstacles] = processor_->filterGroundPointCloud2(msg.data.data(), n, L.point_step, L.off_x, L.off_y, L.off_z);
             if (!ground.empty()) ground_pub_->publish(toMsg(ground, msg.header));            // empty clouds are not
             if (!obstacles.empty()) obstacles_pub_->publish(toMsg(obstacles, msg.header));   // published (node.cpp:116,136)
             publishMarkers(ground.size(), obstacles.size(), msg.header);

@@ -72,6 +72,8 @@ struct rpw_handle {
     // Off by default; a hipGraph capture of the grouped pipeline is what would make it pay.
     uint64_t group_bytes = 0;
     float* d_in = nullptr;
+    unsigned char* d_raw = nullptr;      // raw PointCloud2 bytes (rpw_segment_pointcloud2)
+    size_t raw_bytes = 0;
     uint8_t* d_labels = nullptr;
     float* d_res = nullptr;
 
@@ -106,7 +108,8 @@ void free_device(rpw_handle* h)
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(h->d_bounds); F(h->d_offsets); F(h->d_hist); F(h->d_patch_begin); F(h->d_patches);
     F(h->d_ctrl); F(h->d_bucket_list); F(h->d_sx); F(h->d_sy); F(h->d_sz); F(h->d_ax); F(h->d_ay); F(h->d_az);
-    F(h->d_sidx); F(h->d_mask); F(h->d_tp); F(h->d_tdir); F(h->d_stats); F(h->d_nodes); F(h->d_in); F(h->d_labels); F(h->d_res);
+    F(h->d_sidx); F(h->d_mask); F(h->d_tp); F(h->d_tdir); F(h->d_stats); F(h->d_nodes); F(h->d_in); F(h->d_raw); F(h->d_labels); F(h->d_res);
+    h->raw_bytes = 0;
     for (int i = 0; i < kStageSlots; ++i) {
         if (h->h_offsets[i]) { (void)hipHostFree(h->h_offsets[i]); h->h_offsets[i] = nullptr; }
         if (h->stage_ev[i]) { (void)hipEventDestroy(h->stage_ev[i]); h->stage_ev[i] = nullptr; }
@@ -229,8 +232,10 @@ void timed(rpw_handle* h, int kernel, hipStream_t s, Launch launch)
     if (h->pending.size() > 8192) drain_profile(h);
 }
 
-rpw_status run_batch(rpw_handle* h, const float* d_xyz, const uint32_t* frame_offsets, uint32_t n_frames,
-                     uint8_t* d_labels, float* d_residual, hipStream_t stream)
+struct InputLayout { uint32_t stride = 12, off[3] = {0, 4, 8}; };
+
+rpw_status run_batch(rpw_handle* h, const void* d_xyz, const uint32_t* frame_offsets, uint32_t n_frames,
+                     uint8_t* d_labels, float* d_residual, hipStream_t stream, const InputLayout& lay = InputLayout())
 {
     if (!frame_offsets) return fail(h, RPW_ERR_INVALID, "frame_offsets is null");
     if (n_frames > h->max_frames) return fail(h, RPW_ERR_CAPACITY, "n_frames %u > capacity %u", n_frames, h->max_frames);
@@ -262,7 +267,8 @@ rpw_status run_batch(rpw_handle* h, const float* d_xyz, const uint32_t* frame_of
     DevParams p;
     p.cfg = h->cfg; p.tab = h->tab; p.bounds = h->d_bounds; p.S = h->S; p.P = h->P; p.PB = h->PB;
     p.n_frames = F; p.n_tiles = tiles; p.frame_first = 0; p.frame_count = F; p.tile_first = 0; p.tile_count = tiles; p.frame_off = h->d_offsets; p.tile_base = h->d_offsets + (F + 1);
-    p.xyz = reinterpret_cast<const P3*>(d_xyz); p.labels = d_labels; p.residual = d_residual;
+    p.xyz = reinterpret_cast<const P3*>(d_xyz); p.in_stride = lay.stride;
+    p.in_off[0] = lay.off[0]; p.in_off[1] = lay.off[1]; p.in_off[2] = lay.off[2]; p.labels = d_labels; p.residual = d_residual;
     p.hist = h->d_hist; p.patch_begin = h->d_patch_begin; p.patches = h->d_patches;
     p.bucket_count = h->d_ctrl; p.bucket_list = h->d_bucket_list; p.list_stride = h->max_frames * (uint32_t)h->P;
     p.tp = h->d_tp; p.tdir = h->d_tdir;
@@ -443,6 +449,41 @@ rpw_status rpw_segment(rpw_handle* h, const float* xyz, uint32_t n, uint8_t* lab
     if (n) RPW_HIP(h, hipMemcpyAsync(h->d_in, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
     const uint32_t off[2] = {0, n};
     rpw_status st = run_batch(h, h->d_in, off, 1, h->d_labels, residual ? h->d_res : nullptr, s);
+    if (st != RPW_OK) return st;
+    if (n) RPW_HIP(h, hipMemcpyAsync(labels, h->d_labels, n, hipMemcpyDeviceToHost, s));
+    if (n && residual) RPW_HIP(h, hipMemcpyAsync(residual, h->d_res, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
+    RPW_HIP(h, hipStreamSynchronize(s));
+    if (stats) RPW_HIP(h, hipMemcpy(stats, h->d_stats, sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
+    return RPW_OK;
+}
+
+rpw_status rpw_segment_pointcloud2(rpw_handle* h, const uint8_t* data, uint32_t n, uint32_t point_step,
+                                   uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                                   uint8_t* labels, float* residual, rpw_frame_stats* stats)
+{
+    if (!h) return RPW_ERR_INVALID;
+    if (n && (!data || !labels)) return fail(h, RPW_ERR_INVALID, "null pointer");
+    if (point_step < 12 || (point_step & 3u) || (off_x & 3u) || (off_y & 3u) || (off_z & 3u) ||
+        off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step)
+        return fail(h, RPW_ERR_INVALID, "PointCloud2 layout: point_step %u, x/y/z offsets %u/%u/%u must be 4-byte aligned FLOAT32 fields inside the record",
+                    point_step, off_x, off_y, off_z);
+    if (n > h->max_points) return fail(h, RPW_ERR_CAPACITY, "frame of %u points > capacity %u", n, h->max_points);
+    RPW_HIP(h, hipSetDevice(h->device));
+    const size_t N = h->max_points ? h->max_points : 1;
+    const size_t need = (size_t)n * point_step;
+    if (need > h->raw_bytes) {                       // staging for the raw message bytes, grown on demand
+        if (h->d_raw) { (void)hipFree(h->d_raw); h->d_raw = nullptr; h->raw_bytes = 0; }
+        RPW_HIP(h, hipMalloc(&h->d_raw, need));
+        h->raw_bytes = need;
+    }
+    if (!h->d_labels) RPW_HIP(h, hipMalloc(&h->d_labels, N));
+    if (residual && !h->d_res) RPW_HIP(h, hipMalloc(&h->d_res, N * sizeof(float)));
+    if (!h->own_stream) RPW_HIP(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    hipStream_t s = h->own_stream;
+    if (n) RPW_HIP(h, hipMemcpyAsync(h->d_raw, data, need, hipMemcpyHostToDevice, s));
+    const uint32_t off[2] = {0, n};
+    InputLayout lay; lay.stride = point_step; lay.off[0] = off_x; lay.off[1] = off_y; lay.off[2] = off_z;
+    rpw_status st = run_batch(h, h->d_raw, off, 1, h->d_labels, residual ? h->d_res : nullptr, s, lay);
     if (st != RPW_OK) return st;
     if (n) RPW_HIP(h, hipMemcpyAsync(labels, h->d_labels, n, hipMemcpyDeviceToHost, s));
     if (n && residual) RPW_HIP(h, hipMemcpyAsync(residual, h->d_res, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));

@@ -38,7 +38,9 @@ struct DevParams {
     const uint32_t* frame_off;    // [F+1] device copy
     const uint32_t* tile_base;    // [F+1] first tile of each frame
 
-    const P3* xyz;                // input AoS
+    const P3* xyz;                // input records: packed Point3D when in_stride == 12, else byte records
+    uint32_t  in_stride;          // bytes per input record
+    uint32_t  in_off[3];          // byte offsets of the FLOAT32 x, y, z fields inside a record (multiples of 4)
     uint8_t*  labels;
     float*    residual;           // may be null
 

@@ -63,6 +63,21 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* red /*
 
 
 // ------------------------------------------------------------------------------------------
+// input record: packed Point3D (12 B, one dwordx3 load) or a PointCloud2-style record (x, y, z FLOAT32 at
+// byte offsets inside a point_step-byte record: three dword loads)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ P3 load_point(const DevParams& p, uint32_t i)
+{
+    if (p.in_stride == 12u) return p.xyz[i];
+    const unsigned char* rec = reinterpret_cast<const unsigned char*>(p.xyz) + (size_t)i * p.in_stride;
+    P3 q;
+    q.x = *reinterpret_cast<const float*>(rec + p.in_off[0]);
+    q.y = *reinterpret_cast<const float*>(rec + p.in_off[1]);
+    q.z = *reinterpret_cast<const float*>(rec + p.in_off[2]);
+    return q;
+}
+
+// ------------------------------------------------------------------------------------------
 // tile -> frame lookup
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t frame_of_tile(const uint32_t* __restrict__ tile_base, uint32_t n_frames, uint32_t tile)
@@ -81,6 +96,7 @@ __device__ __forceinline__ uint32_t frame_of_tile(const uint32_t* __restrict__ t
 // The per-patch contiguous arrays are then assembled by patch_fit itself (its gather prologue), where
 // bandwidth is idle, so the binning pass touches HBM with 12 + 16 (+1 label) bytes per point.
 // ------------------------------------------------------------------------------------------
+template <bool STRIDED>
 __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
 {
     extern __shared__ uint32_t lds_u32[];
@@ -107,7 +123,7 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
     for (int r = 0; r < kTileItems; ++r) {
         const uint32_t i = wbase + r * kWave + lane;
         q[r].x = q[r].y = q[r].z = 1.0f;
-        if (i < nf) q[r] = p.xyz[fo + i];
+        if (i < nf) q[r] = STRIDED ? load_point(p, fo + i) : p.xyz[fo + i];     // packed: one dwordx3 load
     }
     int cls[kTileItems];
     uint32_t loff[kTileItems];
@@ -937,7 +953,7 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
             if ((gm[i] >> final_bit) & 1u) p.labels[fo + orig] = RPW_LABEL_GROUND;
             if (p.residual) {
                 float x, y, z;
-                if (permuted) { const P3 q = p.xyz[fo + orig]; x = q.x; y = q.y; z = q.z; }
+                if (permuted) { const P3 q = load_point(p, fo + orig); x = q.x; y = q.y; z = q.z; }
                 else { x = gx[i]; y = gy[i]; z = gz[i]; }
                 p.residual[fo + orig] = plane_dist(x, y, z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
             }
@@ -989,7 +1005,10 @@ __global__ void debug_eig3_kernel(const float* cov, float* nrm, uint32_t n)
 void launch_bin(const DevParams& p, hipStream_t s)
 {
     if (p.tile_count == 0) return;
-    hipLaunchKernelGGL(bin_tile_kernel, dim3(p.tile_count), dim3(kTileThreads), (size_t)(5 * p.PB + p.S + 1) * 4, s, p);
+    if (p.in_stride == 12u)
+        hipLaunchKernelGGL(bin_tile_kernel<false>, dim3(p.tile_count), dim3(kTileThreads), (size_t)(5 * p.PB + p.S + 1) * 4, s, p);
+    else
+        hipLaunchKernelGGL(bin_tile_kernel<true>, dim3(p.tile_count), dim3(kTileThreads), (size_t)(5 * p.PB + p.S + 1) * 4, s, p);
 }
 void launch_scan(const DevParams& p, hipStream_t s)
 {

@@ -6,6 +6,7 @@
 #include <cassert>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -63,6 +64,16 @@ int main()
     assert(def.getConfig().num_sectors == 12);
     auto r4 = def.filterGroundPoints(big);
     assert(r4.first.size() + r4.second.size() == big.size());
+
+    // PointCloud2 bytes (16-byte records) give the same pair as the vector interface
+    {
+        std::vector<unsigned char> bytes(points.size() * 16, 0x5A);
+        for (size_t i = 0; i < points.size(); ++i) std::memcpy(&bytes[16 * i], &points[i].x, 12);
+        auto r6 = patchwork.filterGroundPointCloud2(bytes.data(), points.size(), 16, 0, 4, 8);
+        auto r7 = patchwork.filterGroundPoints(points);
+        assert(r6.first.size() == r7.first.size() && r6.second.size() == r7.second.size());
+        for (size_t i = 0; i < r6.first.size(); ++i) assert(std::memcmp(&r6.first[i], &r7.first[i], 12) == 0);
+    }
 
     // empty input: both empty
     auto r5 = def.filterGroundPoints({});

@@ -221,3 +221,26 @@ def test_randomised_configs_and_clouds(engine_factory):
         labels, res, st = eng.segment(xyz, want_residual=True)
         assert_frame_parity(xyz, labels, res, st, eng.nodes(max(1 << 16, len(xyz))), oc, tag=f"case {it} {kw}")
         eng.close()
+
+
+def test_pointcloud2_records_read_in_place(engine_factory):
+    """PointCloud2 wire format (pcl::PointXYZ 16-byte records, Velodyne-style 32-byte records, odd field
+    order): the binning kernel reads the records in place; results must equal the packed-float3 path."""
+    xyz = W.c2_hdl64(9)[::2].copy()
+    xyz[5] = np.nan
+    pc, oc = cfg_pair(max_split_depth=3, max_iter=4, th_dist=0.05)        # a few splits, so the post-split residual gather runs too
+    eng = engine_factory(pc, max_points=len(xyz), max_frames=1)
+    want_l, want_r, want_s = eng.segment(xyz, want_residual=True)
+    assert_frame_parity(xyz, want_l, want_r, want_s, None, oc, check_nodes=False, tag="packed")
+    n = len(xyz)
+    for step, (ox, oy, oz) in ((16, (0, 4, 8)), (32, (0, 4, 8)), (24, (12, 4, 20))):
+        rec = np.full((n, step), 0xAB, np.uint8)
+        rec[:, ox:ox + 4] = xyz[:, 0:1].copy().view(np.uint8)
+        rec[:, oy:oy + 4] = xyz[:, 1:2].copy().view(np.uint8)
+        rec[:, oz:oz + 4] = xyz[:, 2:3].copy().view(np.uint8)
+        l, r, s = eng.segment_pointcloud2(rec.reshape(-1), n, step, ox, oy, oz, want_residual=True)
+        assert np.array_equal(l, want_l) and np.array_equal(r, want_r, equal_nan=True), (step, ox, oy, oz)
+        for k in ("n_ground", "n_nodes", "n_splits", "total_iterations"):
+            assert s[k] == want_s[k]
+    with pytest.raises(rpw_amd.RpwError):
+        eng.segment_pointcloud2(np.zeros(64, np.uint8), 4, 16, 0, 4, 14)      # misaligned field
