@@ -77,7 +77,8 @@ enum {
     RPW_LABEL_NONGROUND = 0,
     RPW_LABEL_GROUND    = 1,
     RPW_LABEL_DROPPED   = 2,  /* non-finite coordinate (cleanPoints, recursive_patchwork.cpp:19-35) */
-    RPW_LABEL_OUTSIDE   = 3   /* finite, sqrt(x^2+y^2) > filtering_radius                           */
+    RPW_LABEL_OUTSIDE   = 3,  /* finite, sqrt(x^2+y^2) > filtering_radius                           */
+    RPW_LABEL_EGO       = 4   /* only with the fusion pre-step: removed by the ego-radius filter, in no cloud */
 };
 
 typedef struct rpw_frame_stats {
@@ -148,6 +149,26 @@ rpw_status  rpw_segment(rpw_handle* h, const float* xyz, uint32_t n, uint8_t* la
 rpw_status  rpw_segment_pointcloud2(rpw_handle* h, const uint8_t* data, uint32_t n, uint32_t point_step,
                                     uint32_t off_x, uint32_t off_y, uint32_t off_z,
                                     uint8_t* labels, float* residual, rpw_frame_stats* stats);
+
+/* ---- LidarFusion pre-step, fused into the binning kernel's load stage --------------------------------------
+ * reference src/recursive_patchwork/src/lidar_fusion.cpp:42-86 (fuseLidarPointClouds), :88-107 (processSingleLidar),
+ * :109-126 (applyRotation2D), :148-159 + :184-187 (removeEgoVehicle). A frame is then the concatenation of the
+ * RAW clouds of the configured sensors; every point is yaw-rotated by its sensor's angle (when |angle| > 1e-6
+ * degrees) and dropped when sqrtf(x*x + y*y) <= ego_radius (label RPW_LABEL_EGO); the remaining points, in
+ * sensor order, are exactly the cloud fuseLidarPointClouds returns, and they are segmented as usual
+ * (stats.n_in counts them). Residuals and the recursion trace refer to the rotated points. */
+typedef struct rpw_sensor {
+    float rotation_deg;   /* LidarConfig::rotation_angle (recursive_patchwork.hpp:41) */
+    float ego_radius;     /* LidarConfig::ego_radius     (recursive_patchwork.hpp:42) */
+} rpw_sensor;
+rpw_status  rpw_set_sensors(rpw_handle* h, uint32_t n_sensors, const rpw_sensor* sensors);   /* n_sensors <= 8; 0 = off */
+/* one frame, host pointers: sensor k's raw cloud is xyz[sensor_offsets[k] .. sensor_offsets[k+1]) */
+rpw_status  rpw_segment_fused(rpw_handle* h, const float* xyz, const uint32_t* sensor_offsets,
+                              uint8_t* labels, float* residual, rpw_frame_stats* stats);
+/* device-resident batch: sensor_offsets is a HOST array [n_frames][n_sensors + 1], relative to each frame */
+rpw_status  rpw_segment_batch_device_fused(rpw_handle* h, const float* d_xyz, const uint32_t* frame_offsets,
+                                           const uint32_t* sensor_offsets, uint32_t n_frames, uint8_t* d_labels,
+                                           float* d_residual, void* stream);
 
 /* Device-resident batch, asynchronous on `stream` (a hipStream_t, NULL = default stream).
  *   d_xyz          device pointer, frames concatenated, AoS

@@ -450,6 +450,39 @@ void make_tables(const rpwo_config& cfg, float edges[9], std::vector<float>& bou
 
 extern "C" {
 
+// LidarFusion::fuseLidarPointClouds restated (reference src/lidar_fusion.cpp:42-86,88-126,148-159,184-187):
+// per sensor: yaw rotation when |angle| > 1e-6 (cosf/sinf of the float radians, x*c - y*s, x*s + y*c), then
+// removeEgoVehicle (points with sqrtf(x*x + y*y) <= radius are dropped), then concatenation in sensor order.
+// xyz holds the raw clouds back to back, sensor k = [sensor_off[k], sensor_off[k+1]). out_src[j] = raw index.
+int rpwo_fuse(const float* xyz, const uint32_t* sensor_off, uint32_t n_sensors, const float* rotation_deg,
+              const float* ego_radius, float* out_xyz, uint32_t* out_src, uint32_t* n_out)
+{
+    uint32_t m = 0;
+    for (uint32_t k = 0; k < n_sensors; ++k) {
+        const float angle_degrees = rotation_deg[k];
+        const bool rotate = std::abs(angle_degrees) > 1e-6f;
+        float angle_rad = angle_degrees * M_PI / 180.0f;
+        float cos_a = std::cos(angle_rad);
+        float sin_a = std::sin(angle_rad);
+        for (uint32_t i = sensor_off[k]; i < sensor_off[k + 1]; ++i) {
+            float x = xyz[3 * i], y = xyz[3 * i + 1];
+            const float z = xyz[3 * i + 2];
+            if (rotate) {
+                const float rx = x * cos_a - y * sin_a;
+                const float ry = x * sin_a + y * cos_a;
+                x = rx; y = ry;
+            }
+            const float distance_2d = std::sqrt(x * x + y * y);
+            if (distance_2d <= ego_radius[k]) continue;
+            out_xyz[3 * m] = x; out_xyz[3 * m + 1] = y; out_xyz[3 * m + 2] = z;
+            if (out_src) out_src[m] = i;
+            ++m;
+        }
+    }
+    *n_out = m;
+    return 0;
+}
+
 void rpwo_set_iter_trace(uint64_t* buf, uint32_t cap) { g_iter_trace = buf; g_iter_cap = cap; g_iter_n = 0; }
 uint32_t rpwo_iter_trace_count(void) { return g_iter_n; }
 

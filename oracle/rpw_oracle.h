@@ -98,6 +98,11 @@ int rpwo_filter_ground_points(const rpwo_config* cfg, const float* xyz, uint32_t
                               float* ground_xyz, uint32_t* n_ground,
                               float* nonground_xyz, uint32_t* n_nonground);
 
+/* LidarFusion pre-step (reference src/lidar_fusion.cpp:42-126,148-159,184-187): per-sensor yaw rotation,
+ * ego-radius removal, concatenation. out_xyz / out_src must hold sensor_off[n_sensors] entries. */
+int rpwo_fuse(const float* xyz, const uint32_t* sensor_off, uint32_t n_sensors, const float* rotation_deg,
+              const float* ego_radius, float* out_xyz, uint32_t* out_src, uint32_t* n_out);
+
 /* analysis aid: record {patch, depth, iter, inlier count, mask hash} (5 x uint64) for every loop
  * iteration of the following rpwo_segment calls; buf = NULL switches it off */
 void     rpwo_set_iter_trace(uint64_t* buf, uint32_t cap);

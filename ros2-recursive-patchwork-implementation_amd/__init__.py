@@ -24,7 +24,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("RPW_LIB", os.path.join(PKG_DIR, "librpw_hip.so"))
 
-LABEL_NONGROUND, LABEL_GROUND, LABEL_DROPPED, LABEL_OUTSIDE = 0, 1, 2, 3
+LABEL_NONGROUND, LABEL_GROUND, LABEL_DROPPED, LABEL_OUTSIDE, LABEL_EGO = 0, 1, 2, 3, 4
 K_BIN, K_SCAN, K_FIT, K_COUNT = 0, 1, 2, 3
 KERNEL_NAMES = ("bin_tile", "scan_offsets", "patch_fit")
 
@@ -123,6 +123,12 @@ def load_library():
     L.rpw_segment.restype = i32
     L.rpw_segment_pointcloud2.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, vp, C.POINTER(CFrameStats)]
     L.rpw_segment_pointcloud2.restype = i32
+    L.rpw_set_sensors.argtypes = [vp, u32, vp]
+    L.rpw_set_sensors.restype = i32
+    L.rpw_segment_fused.argtypes = [vp, vp, vp, vp, vp, C.POINTER(CFrameStats)]
+    L.rpw_segment_fused.restype = i32
+    L.rpw_segment_batch_device_fused.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp]
+    L.rpw_segment_batch_device_fused.restype = i32
     L.rpw_segment_batch_device.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     L.rpw_segment_batch_device.restype = i32
     L.rpw_get_batch_stats.argtypes = [vp, vp, u32]
@@ -147,7 +153,8 @@ def load_library():
 
 EXPORTED_SYMBOLS = (
     "rpw_default_config", "rpw_abi_version", "rpw_create", "rpw_destroy", "rpw_set_config", "rpw_get_config",
-    "rpw_last_error", "rpw_segment", "rpw_segment_pointcloud2", "rpw_segment_batch_device", "rpw_get_batch_stats", "rpw_set_trace",
+    "rpw_last_error", "rpw_segment", "rpw_segment_pointcloud2", "rpw_set_sensors", "rpw_segment_fused",
+    "rpw_segment_batch_device_fused", "rpw_segment_batch_device", "rpw_get_batch_stats", "rpw_set_trace",
     "rpw_get_nodes", "rpw_set_profiling", "rpw_get_kernel_ms", "rpw_debug_angles", "rpw_debug_eig3",
     "rpw_debug_angles_host",
 )
@@ -223,6 +230,31 @@ class Engine:
                                                     labels.ctypes.data, res.ctypes.data if res is not None else None,
                                                     C.byref(st)))
         return labels, res, {k: getattr(st, k) for k, _ in CFrameStats._fields_}
+
+    def set_sensors(self, rotation_deg, ego_radius):
+        """LidarFusion pre-step: one (rotation_angle [deg], ego_radius) pair per sensor; empty lists switch it off."""
+        cfg = np.ascontiguousarray(np.column_stack([np.asarray(rotation_deg, np.float32), np.asarray(ego_radius, np.float32)]).reshape(-1, 2), np.float32)
+        self._check(self._L.rpw_set_sensors(self._h, len(cfg), cfg.ctypes.data if len(cfg) else None))
+        self.n_sensors = len(cfg)
+
+    def segment_fused(self, clouds, want_residual: bool = False):
+        """One frame = raw clouds of the configured sensors -> (labels per RAW point, residual, stats)."""
+        raw = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float32).reshape(-1, 3) for c in clouds], axis=0))
+        off = np.zeros(len(clouds) + 1, np.uint32); off[1:] = np.cumsum([len(c) for c in clouds])
+        n = len(raw)
+        labels = np.empty(n, np.uint8)
+        res = np.empty(n, np.float32) if want_residual else None
+        st = CFrameStats()
+        self._check(self._L.rpw_segment_fused(self._h, raw.ctypes.data, off.ctypes.data, labels.ctypes.data,
+                                              res.ctypes.data if res is not None else None, C.byref(st)))
+        return labels, res, {k: getattr(st, k) for k, _ in CFrameStats._fields_}
+
+    def segment_batch_device_fused(self, d_xyz_ptr: int, frame_offsets, sensor_offsets, d_labels_ptr: int,
+                                   d_residual_ptr: int | None = None, stream: int | None = None):
+        off = np.ascontiguousarray(frame_offsets, dtype=np.uint32)
+        so = np.ascontiguousarray(sensor_offsets, dtype=np.uint32)
+        self._check(self._L.rpw_segment_batch_device_fused(self._h, d_xyz_ptr, off.ctypes.data, so.ctypes.data, len(off) - 1,
+                                                           d_labels_ptr, d_residual_ptr or None, stream or None))
 
     def segment_batch_device(self, d_xyz_ptr: int, frame_offsets: np.ndarray, d_labels_ptr: int,
                              d_residual_ptr: int | None = None, stream: int | None = None):

@@ -2,6 +2,7 @@
 // and the C-ABI (include/rpw.h). No arithmetic of the path happens here.
 #include "recursive_patchwork.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <iostream>
@@ -113,6 +114,53 @@ RecursivePatchwork::filterGroundPointCloud2(const unsigned char* data, size_t n,
         else if (labels[i] == RPW_LABEL_NONGROUND) non_ground.push_back(point(i));
     }
     for (size_t i = 0; i < n; ++i) if (labels[i] == RPW_LABEL_OUTSIDE) non_ground.push_back(point(i));
+    return {ground, non_ground};
+}
+
+std::pair<std::vector<Point3D>, std::vector<Point3D>>
+RecursivePatchwork::fuseAndFilterGroundPoints(const std::vector<std::vector<Point3D>>& clouds,
+                                              const std::vector<LidarConfig>& configs)
+{
+    const size_t ns = std::min(clouds.size(), configs.size());          // as fuseLidarPointClouds does (lidar_fusion.cpp:59)
+    if (ns == 0) return {{}, {}};
+    std::vector<rpw_sensor> sensors(ns);
+    std::vector<uint32_t> off(ns + 1, 0);
+    for (size_t k = 0; k < ns; ++k) {
+        sensors[k].rotation_deg = configs[k].rotation_angle; sensors[k].ego_radius = configs[k].ego_radius;
+        off[k + 1] = off[k] + (uint32_t)clouds[k].size();
+    }
+    std::vector<Point3D> raw; raw.reserve(off[ns]);
+    for (size_t k = 0; k < ns; ++k) raw.insert(raw.end(), clouds[k].begin(), clouds[k].end());
+    ensure(raw.size());
+    if (rpw_set_sensors(handle_, (uint32_t)ns, sensors.data()) != RPW_OK)
+        throw std::runtime_error(std::string("RecursivePatchwork: rpw_set_sensors failed: ") + rpw_last_error(handle_));
+    std::vector<unsigned char> labels(raw.size());
+    rpw_frame_stats st;
+    const rpw_status rc = rpw_segment_fused(handle_, raw.empty() ? nullptr : &raw[0].x, off.data(), labels.data(), nullptr, &st);
+    (void)rpw_set_sensors(handle_, 0, nullptr);
+    if (rc != RPW_OK) throw std::runtime_error(std::string("RecursivePatchwork: rpw_segment_fused failed: ") + rpw_last_error(handle_));
+    // the output points are the FUSED (rotated) ones: same expressions as lidar_fusion.cpp:109-126
+    for (size_t k = 0; k < ns; ++k) {
+        const float angle_degrees = configs[k].rotation_angle;
+        if (!(std::abs(angle_degrees) > 1e-6f)) continue;
+        float angle_rad = angle_degrees * M_PI / 180.0f;
+        const float cos_a = std::cos(angle_rad), sin_a = std::sin(angle_rad);
+        for (uint32_t i = off[k]; i < off[k + 1]; ++i) {
+            const float x = raw[i].x * cos_a - raw[i].y * sin_a;
+            const float y = raw[i].x * sin_a + raw[i].y * cos_a;
+            raw[i].x = x; raw[i].y = y;
+        }
+    }
+    std::vector<Point3D> ground, non_ground;
+    if (st.n_zone < 3) {
+        for (size_t i = 0; i < raw.size(); ++i) if (labels[i] != RPW_LABEL_DROPPED && labels[i] != RPW_LABEL_EGO) non_ground.push_back(raw[i]);
+        return {ground, non_ground};
+    }
+    for (size_t i = 0; i < raw.size(); ++i) {
+        if (labels[i] == RPW_LABEL_GROUND) ground.push_back(raw[i]);
+        else if (labels[i] == RPW_LABEL_NONGROUND) non_ground.push_back(raw[i]);
+    }
+    for (size_t i = 0; i < raw.size(); ++i) if (labels[i] == RPW_LABEL_OUTSIDE) non_ground.push_back(raw[i]);
     return {ground, non_ground};
 }
 

@@ -37,6 +37,14 @@ struct PatchworkConfig {
     int max_split_depth = 1000;
 };
 
+// LiDAR configuration, as the reference's (recursive_patchwork.hpp:39-44)
+struct LidarConfig {
+    int lidar_id;
+    std::string topic_name;
+    float rotation_angle;  // degrees
+    float ego_radius = 2.5f;
+};
+
 class RecursivePatchwork {
 public:
     RecursivePatchwork(const PatchworkConfig& config = PatchworkConfig{});
@@ -58,6 +66,13 @@ public:
     std::pair<std::vector<Point3D>, std::vector<Point3D>>
     filterGroundPointCloud2(const unsigned char* data, size_t n, unsigned point_step,
                             unsigned off_x, unsigned off_y, unsigned off_z);
+
+    // Build-side addition: LidarFusion::fuseLidarPointClouds (reference src/lidar_fusion.cpp:42-86) followed by
+    // filterGroundPoints in ONE device pass: the per-sensor yaw rotation and ego-radius removal run in the
+    // binning kernel's load stage. Returns the same pair filterGroundPoints(fuse(clouds)) would.
+    std::pair<std::vector<Point3D>, std::vector<Point3D>>
+    fuseAndFilterGroundPoints(const std::vector<std::vector<Point3D>>& lidar_point_clouds,
+                              const std::vector<LidarConfig>& lidar_configs);
 
     std::vector<Point3D> cleanPoints(const std::vector<Point3D>& points);
 

@@ -37,8 +37,11 @@ struct rpw_handle {
     PolarTables tab;
     float* d_bounds = nullptr;
 
+    // LidarFusion pre-step (off when sensors.n == 0)
+    SensorTable sensors;
+
     // batch buffers
-    uint32_t* d_offsets = nullptr;       // [2*(F+1)] frame_off then tile_base
+    uint32_t* d_offsets = nullptr;       // [2*(F+1)] frame_off then tile_base, then [F][kMaxSensors+1] sensor offsets
     uint32_t* h_offsets[kStageSlots] = {};   // pinned staging ring
     hipEvent_t stage_ev[kStageSlots] = {};
     bool stage_used[kStageSlots] = {};
@@ -168,14 +171,15 @@ rpw_status allocate(rpw_handle* h)
 {
     free_device(h);
     const size_t N = h->max_points ? h->max_points : 1, F = h->max_frames ? h->max_frames : 1;
-    h->S = h->cfg.num_sectors; h->P = 8 * h->S; h->PB = (h->P + 3 + 3) & ~3;
+    h->S = h->cfg.num_sectors; h->P = 8 * h->S; h->PB = (h->P + 4 + 3) & ~3;       // patch classes + {no patch, outside, non-finite, ego-removed}
     std::vector<float> bounds;
     build_tables(h->cfg, h->tab, bounds);
     RPW_HIP(h, hipMalloc(&h->d_bounds, bounds.size() * sizeof(float)));
     RPW_HIP(h, hipMemcpy(h->d_bounds, bounds.data(), bounds.size() * sizeof(float), hipMemcpyHostToDevice));
-    RPW_HIP(h, hipMalloc(&h->d_offsets, 2 * (F + 1) * sizeof(uint32_t)));
+    const size_t off_words = 2 * (F + 1) + F * (kMaxSensors + 1);
+    RPW_HIP(h, hipMalloc(&h->d_offsets, off_words * sizeof(uint32_t)));
     for (int i = 0; i < kStageSlots; ++i) {
-        RPW_HIP(h, hipHostMalloc((void**)&h->h_offsets[i], 2 * (F + 1) * sizeof(uint32_t), hipHostMallocDefault));
+        RPW_HIP(h, hipHostMalloc((void**)&h->h_offsets[i], off_words * sizeof(uint32_t), hipHostMallocDefault));
         RPW_HIP(h, hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
     }
     h->max_tiles = (uint32_t)(N / kTilePoints + F);
@@ -235,7 +239,8 @@ void timed(rpw_handle* h, int kernel, hipStream_t s, Launch launch)
 struct InputLayout { uint32_t stride = 12, off[3] = {0, 4, 8}; };
 
 rpw_status run_batch(rpw_handle* h, const void* d_xyz, const uint32_t* frame_offsets, uint32_t n_frames,
-                     uint8_t* d_labels, float* d_residual, hipStream_t stream, const InputLayout& lay = InputLayout())
+                     uint8_t* d_labels, float* d_residual, hipStream_t stream, const InputLayout& lay = InputLayout(),
+                     const uint32_t* sensor_offsets = nullptr /* [F][sensors.n + 1], frame-relative */)
 {
     if (!frame_offsets) return fail(h, RPW_ERR_INVALID, "frame_offsets is null");
     if (n_frames > h->max_frames) return fail(h, RPW_ERR_CAPACITY, "n_frames %u > capacity %u", n_frames, h->max_frames);
@@ -258,8 +263,23 @@ rpw_status run_batch(rpw_handle* h, const void* d_xyz, const uint32_t* frame_off
         if (f < F) tiles += (frame_offsets[f + 1] - frame_offsets[f] + kTilePoints - 1) / kTilePoints;
     }
     if (ho[0] != 0) return fail(h, RPW_ERR_INVALID, "frame_offsets[0] must be 0");
+    const int ns = sensor_offsets ? h->sensors.n : 0;
+    size_t copy_words = 2 * (size_t)(F + 1);
+    if (ns > 0) {
+        uint32_t* so = ho + 2 * (F + 1);
+        for (uint32_t f = 0; f < F; ++f) {
+            const uint32_t nf = frame_offsets[f + 1] - frame_offsets[f];
+            const uint32_t* src = sensor_offsets + (size_t)f * (ns + 1);
+            if (src[0] != 0 || src[ns] != nf) return fail(h, RPW_ERR_INVALID, "sensor offsets of frame %u must run from 0 to the frame size", f);
+            for (int j = 0; j <= ns; ++j) {
+                if (j && src[j] < src[j - 1]) return fail(h, RPW_ERR_INVALID, "sensor offsets of frame %u not monotone", f);
+                so[(size_t)f * (ns + 1) + j] = src[j];
+            }
+        }
+        copy_words += (size_t)F * (ns + 1);
+    }
     if (tiles > h->max_tiles) return fail(h, RPW_ERR_CAPACITY, "tile count %u > capacity %u", tiles, h->max_tiles);
-    RPW_HIP(h, hipMemcpyAsync(h->d_offsets, ho, 2 * (F + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    RPW_HIP(h, hipMemcpyAsync(h->d_offsets, ho, copy_words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     RPW_HIP(h, hipEventRecord(h->stage_ev[slot], stream));
     h->stage_used[slot] = true;
     RPW_HIP(h, hipMemsetAsync(h->d_ctrl, 0, (kBuckets + 4) * sizeof(uint32_t), stream));
@@ -268,7 +288,9 @@ rpw_status run_batch(rpw_handle* h, const void* d_xyz, const uint32_t* frame_off
     p.cfg = h->cfg; p.tab = h->tab; p.bounds = h->d_bounds; p.S = h->S; p.P = h->P; p.PB = h->PB;
     p.n_frames = F; p.n_tiles = tiles; p.frame_first = 0; p.frame_count = F; p.tile_first = 0; p.tile_count = tiles; p.frame_off = h->d_offsets; p.tile_base = h->d_offsets + (F + 1);
     p.xyz = reinterpret_cast<const P3*>(d_xyz); p.in_stride = lay.stride;
-    p.in_off[0] = lay.off[0]; p.in_off[1] = lay.off[1]; p.in_off[2] = lay.off[2]; p.labels = d_labels; p.residual = d_residual;
+    p.in_off[0] = lay.off[0]; p.in_off[1] = lay.off[1]; p.in_off[2] = lay.off[2]; p.labels = d_labels;
+    p.sensors = h->sensors; if (ns == 0) p.sensors.n = 0;
+    p.sensor_off = h->d_offsets + 2 * (F + 1); p.residual = d_residual;
     p.hist = h->d_hist; p.patch_begin = h->d_patch_begin; p.patches = h->d_patches;
     p.bucket_count = h->d_ctrl; p.bucket_list = h->d_bucket_list; p.list_stride = h->max_frames * (uint32_t)h->P;
     p.tp = h->d_tp; p.tdir = h->d_tdir;
@@ -369,6 +391,7 @@ rpw_status rpw_create(const rpw_config* cfg, int device, uint32_t max_points, ui
     }
     rpw_handle* h = new (std::nothrow) rpw_handle();
     if (!h) return fail(nullptr, RPW_ERR_INVALID, "out of host memory");
+    std::memset(&h->sensors, 0, sizeof h->sensors);
     h->cfg = c; h->device = device; h->max_points = max_points; h->max_frames = max_frames ? max_frames : 1;
     // Streams are created lazily (own_stream by the host-pointer path, aux_stream by the grouped binning
     // pipeline): ROCm multiplexes all streams of a process onto a few hardware queues, and an idle extra
@@ -490,6 +513,77 @@ rpw_status rpw_segment_pointcloud2(rpw_handle* h, const uint8_t* data, uint32_t 
     RPW_HIP(h, hipStreamSynchronize(s));
     if (stats) RPW_HIP(h, hipMemcpy(stats, h->d_stats, sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
     return RPW_OK;
+}
+
+rpw_status rpw_set_sensors(rpw_handle* h, uint32_t n_sensors, const rpw_sensor* sensors)
+{
+    if (!h) return RPW_ERR_INVALID;
+    if (n_sensors > (uint32_t)kMaxSensors) return fail(h, RPW_ERR_UNSUPPORTED, "%u sensors > %d", n_sensors, kMaxSensors);
+    if (n_sensors && !sensors) return fail(h, RPW_ERR_INVALID, "sensors is null");
+    SensorTable t; std::memset(&t, 0, sizeof t);
+    t.n = (int)n_sensors;
+    for (uint32_t k = 0; k < n_sensors; ++k) {
+        // the reference's own expressions (lidar_fusion.cpp:98, 109-111): float radians, cosf / sinf
+        const float angle_degrees = sensors[k].rotation_deg;
+        t.rotate[k] = std::abs(angle_degrees) > 1e-6f ? 1 : 0;
+        float angle_rad = angle_degrees * M_PI / 180.0f;
+        t.cosv[k] = std::cos(angle_rad);
+        t.sinv[k] = std::sin(angle_rad);
+        // d <= ego_radius  <=>  s < min { s : sqrtf(s) > ego_radius }   (sqrtf is correctly rounded and monotone)
+        const float r = sensors[k].ego_radius;
+        float g;
+        if (!(r == r)) g = 0.0f;                              // NaN radius: nothing is <= NaN
+        else if (r < 0.0f) g = 0.0f;
+        else if (std::isinf(r)) g = r;
+        else {
+            const float up = std::nextafter(r, std::numeric_limits<float>::infinity());
+            float s = (float)((double)up * (double)up);
+            if (std::isinf(s)) s = std::numeric_limits<float>::max();
+            while (s > 0.0f && std::sqrt(std::nextafter(s, 0.0f)) >= up) s = std::nextafter(s, 0.0f);
+            while (!(std::sqrt(s) >= up)) { if (s == std::numeric_limits<float>::max()) { s = std::numeric_limits<float>::infinity(); break; } s = std::nextafter(s, std::numeric_limits<float>::infinity()); }
+            g = s;
+        }
+        t.gt_ego[k] = g;
+    }
+    h->sensors = t;
+    return RPW_OK;
+}
+
+rpw_status rpw_segment_fused(rpw_handle* h, const float* xyz, const uint32_t* sensor_offsets,
+                             uint8_t* labels, float* residual, rpw_frame_stats* stats)
+{
+    if (!h) return RPW_ERR_INVALID;
+    if (h->sensors.n <= 0) return fail(h, RPW_ERR_INVALID, "rpw_set_sensors has not been called");
+    if (!sensor_offsets) return fail(h, RPW_ERR_INVALID, "sensor_offsets is null");
+    const uint32_t n = sensor_offsets[h->sensors.n];
+    if (n && (!xyz || !labels)) return fail(h, RPW_ERR_INVALID, "null pointer");
+    if (n > h->max_points) return fail(h, RPW_ERR_CAPACITY, "frame of %u points > capacity %u", n, h->max_points);
+    RPW_HIP(h, hipSetDevice(h->device));
+    const size_t N = h->max_points ? h->max_points : 1;
+    if (!h->d_in) RPW_HIP(h, hipMalloc(&h->d_in, N * 3 * sizeof(float)));
+    if (!h->d_labels) RPW_HIP(h, hipMalloc(&h->d_labels, N));
+    if (residual && !h->d_res) RPW_HIP(h, hipMalloc(&h->d_res, N * sizeof(float)));
+    if (!h->own_stream) RPW_HIP(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    hipStream_t s = h->own_stream;
+    if (n) RPW_HIP(h, hipMemcpyAsync(h->d_in, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+    const uint32_t off[2] = {0, n};
+    rpw_status st = run_batch(h, h->d_in, off, 1, h->d_labels, residual ? h->d_res : nullptr, s, InputLayout(), sensor_offsets);
+    if (st != RPW_OK) return st;
+    if (n) RPW_HIP(h, hipMemcpyAsync(labels, h->d_labels, n, hipMemcpyDeviceToHost, s));
+    if (n && residual) RPW_HIP(h, hipMemcpyAsync(residual, h->d_res, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
+    RPW_HIP(h, hipStreamSynchronize(s));
+    if (stats) RPW_HIP(h, hipMemcpy(stats, h->d_stats, sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
+    return RPW_OK;
+}
+
+rpw_status rpw_segment_batch_device_fused(rpw_handle* h, const float* d_xyz, const uint32_t* frame_offsets,
+                                          const uint32_t* sensor_offsets, uint32_t n_frames, uint8_t* d_labels,
+                                          float* d_residual, void* stream)
+{
+    if (!h) return RPW_ERR_INVALID;
+    if (h->sensors.n <= 0) return fail(h, RPW_ERR_INVALID, "rpw_set_sensors has not been called");
+    if (!sensor_offsets) return fail(h, RPW_ERR_INVALID, "sensor_offsets is null");
+    return run_batch(h, d_xyz, frame_offsets, n_frames, d_labels, d_residual, (hipStream_t)stream, InputLayout(), sensor_offsets);
 }
 
 rpw_status rpw_set_trace(rpw_handle* h, int enable, uint32_t max_nodes)

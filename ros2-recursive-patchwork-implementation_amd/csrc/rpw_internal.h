@@ -14,6 +14,7 @@ constexpr int kTileItems   = 8;                   // points per thread
 constexpr int kTilePoints  = kTileThreads * kTileItems;   // 2048
 constexpr int kWavePoints  = kWave * kTileItems;  // 512: one wave owns a contiguous sub-tile
 constexpr int kMaxSectors  = 128;
+constexpr int kMaxSensors  = 8;                   // LidarFusion pre-step: sensors per frame
 constexpr int kBuckets     = 64;                  // patch-size buckets for largest-first launch order
 constexpr int kStackDepth  = 48;                  // explicit recursion stack (smaller child first => <= log2(n)+2)
 
@@ -23,6 +24,14 @@ struct PatchDesc {
 };
 
 struct P3 { float x, y, z; };
+
+// LidarFusion pre-step folded into the load stage (reference src/lidar_fusion.cpp:88-126,148-159,184-187)
+struct SensorTable {
+    int   n;                        // 0 = no fusion step
+    int   rotate[kMaxSensors];      // |rotation_angle| > 1e-6
+    float cosv[kMaxSensors], sinv[kMaxSensors];
+    float gt_ego[kMaxSensors];      // min { s : sqrtf(s) > ego_radius }: d <= ego_radius  <=>  x*x + y*y < gt_ego
+};
 
 // Everything a kernel needs, passed by value.
 struct DevParams {
@@ -41,6 +50,8 @@ struct DevParams {
     const P3* xyz;                // input records: packed Point3D when in_stride == 12, else byte records
     uint32_t  in_stride;          // bytes per input record
     uint32_t  in_off[3];          // byte offsets of the FLOAT32 x, y, z fields inside a record (multiples of 4)
+    SensorTable sensors;          // fusion pre-step (n = 0: off)
+    const uint32_t* sensor_off;   // [F][sensors.n + 1] frame-relative first point of every sensor's raw cloud
     uint8_t*  labels;
     float*    residual;           // may be null
 

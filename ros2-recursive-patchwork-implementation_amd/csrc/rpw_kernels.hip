@@ -77,6 +77,25 @@ __device__ __forceinline__ P3 load_point(const DevParams& p, uint32_t i)
     return q;
 }
 
+// LidarFusion pre-step for one point of frame f (index i inside the frame): yaw rotation of its sensor, then
+// the ego-radius test. Returns true when the point is removed (inside the ego radius).
+__device__ __forceinline__ bool fuse_point(const DevParams& p, uint32_t f, uint32_t i, P3& q)
+{
+    const SensorTable& t = p.sensors;
+    const uint32_t* so = p.sensor_off + (size_t)f * (t.n + 1);
+    int k = 0;
+    for (int j = 1; j < t.n; ++j) k += (i >= so[j]) ? 1 : 0;
+    float c = t.cosv[0], s = t.sinv[0], g = t.gt_ego[0]; int rot = t.rotate[0];
+#pragma unroll
+    for (int j = 1; j < kMaxSensors; ++j) if (j < t.n && k == j) { c = t.cosv[j]; s = t.sinv[j]; g = t.gt_ego[j]; rot = t.rotate[j]; }
+    if (rot) {
+        const float rx = q.x * c - q.y * s;
+        const float ry = q.x * s + q.y * c;
+        q.x = rx; q.y = ry;
+    }
+    return (q.x * q.x + q.y * q.y) < g;
+}
+
 // ------------------------------------------------------------------------------------------
 // tile -> frame lookup
 // ------------------------------------------------------------------------------------------
@@ -96,7 +115,7 @@ __device__ __forceinline__ uint32_t frame_of_tile(const uint32_t* __restrict__ t
 // The per-patch contiguous arrays are then assembled by patch_fit itself (its gather prologue), where
 // bandwidth is idle, so the binning pass touches HBM with 12 + 16 (+1 label) bytes per point.
 // ------------------------------------------------------------------------------------------
-template <bool STRIDED>
+template <bool STRIDED, bool FUSED>
 __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
 {
     extern __shared__ uint32_t lds_u32[];
@@ -131,16 +150,19 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
     for (int r = 0; r < kTileItems; ++r) {
         const uint32_t i = wbase + r * kWave + lane;
         const bool valid = i < nf;
+        bool ego = false;
+        if (FUSED) ego = valid && fuse_point(p, f, i, q[r]);   // q[r] now holds the rotated point
         bool unsure = false;
         int c = classify_point_fast(q[r].x, q[r].y, q[r].z, p.tab, bnd, unsure);
-        unsure = unsure && valid;
+        unsure = unsure && valid && !ego;
         if (ballot64(unsure) != 0ull) {                    // rare: some lane sits within 1e-4 rad of a sector bound
             if (unsure) c = classify_point_exact(q[r].x, q[r].y, q[r].z, p.tab, bnd);
         }
+        if (FUSED && ego) c = p.P + 3;                     // removed by the fusion step: in no cloud at all
         cls[r] = valid ? c : p.P;
         loff[r] = 0;
         if (valid) {
-            p.labels[fo + i] = (uint8_t)(c <= p.P ? RPW_LABEL_NONGROUND : (c == p.P + 1 ? RPW_LABEL_OUTSIDE : RPW_LABEL_DROPPED));
+            p.labels[fo + i] = (uint8_t)(c <= p.P ? RPW_LABEL_NONGROUND : (c == p.P + 1 ? RPW_LABEL_OUTSIDE : (c == p.P + 2 ? RPW_LABEL_DROPPED : RPW_LABEL_EGO)));
             if (p.residual) p.residual[fo + i] = -1.0f;
         }
         // stable rank inside the wave's sub-tile: one step per distinct class of the row
@@ -174,7 +196,7 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
         if (c < p.P) { hist_out[c] = v; tdir_out[c] = running + ex; tstart[c] = running + ex; }
         running += total;
     }
-    if (tid < 3) hist_out[p.P + tid] = tstart[p.P + tid];          // special classes: totals only
+    if (tid < 4) hist_out[p.P + tid] = tstart[p.P + tid];          // special classes: totals only
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kTileItems; ++r) {
@@ -220,7 +242,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
     // each over a contiguous range of tiles; every load address is known up front, so the walks
     // pipeline instead of paying one L2 round trip per step.
     extern __shared__ uint32_t lds_u32[];
-    const int C = p.P + 3;
+    const int C = p.P + 4;
     int parts = kScanThreads / C; if (parts > 16) parts = 16; if (parts < 1) parts = 1;
     uint32_t* tot = lds_u32;                  // [PB] per-class totals, then patch_begin
     uint32_t* part = lds_u32 + p.PB;          // [parts][PB] partial totals, then exclusive prefix over parts
@@ -250,8 +272,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
     }
     __syncthreads();
     // zone < 3: the reference returns {{}, cleaned} before looking at any patch (recursive_patchwork.cpp:339-341)
-    const bool zone_too_small = (nf - tot[p.P + 2] - tot[p.P + 1]) < 3u;
-    const uint32_t n_dropped = tot[p.P + 2], n_outside = tot[p.P + 1];
+    const uint32_t n_dropped = tot[p.P + 2], n_outside = tot[p.P + 1], n_ego = tot[p.P + 3];
+    const bool zone_too_small = (nf - n_ego - n_dropped - n_outside) < 3u;
     // exclusive prefix over the patch classes, block-wide
     uint32_t running = 0, npatches = 0;
     for (int c0 = 0; c0 < p.P; c0 += kScanThreads) {
@@ -291,8 +313,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
     if (tid == 0) {
         p.patch_begin[(size_t)f * (p.P + 1) + p.P] = running;
         rpw_frame_stats st;
-        st.n_in = nf;
-        st.n_clean = nf - n_dropped;
+        st.n_in = nf - n_ego;                               // the fused cloud (everything, without a fusion step)
+        st.n_clean = st.n_in - n_dropped;
         st.n_zone = st.n_clean - n_outside;
         st.n_ground = 0; st.n_patches = zone_too_small ? 0u : npatches; st.n_nodes = 0; st.n_splits = 0; st.max_depth = 0;
         st.total_iterations = 0; st.chain_addends = 0;
@@ -953,7 +975,11 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
             if ((gm[i] >> final_bit) & 1u) p.labels[fo + orig] = RPW_LABEL_GROUND;
             if (p.residual) {
                 float x, y, z;
-                if (permuted) { const P3 q = load_point(p, fo + orig); x = q.x; y = q.y; z = q.z; }
+                if (permuted) {
+                    P3 q = load_point(p, fo + orig);
+                    if (p.sensors.n) (void)fuse_point(p, (uint32_t)frame, orig, q);     // the point as the fused cloud holds it
+                    x = q.x; y = q.y; z = q.z;
+                }
                 else { x = gx[i]; y = gy[i]; z = gz[i]; }
                 p.residual[fo + orig] = plane_dist(x, y, z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
             }
@@ -1005,10 +1031,15 @@ __global__ void debug_eig3_kernel(const float* cov, float* nrm, uint32_t n)
 void launch_bin(const DevParams& p, hipStream_t s)
 {
     if (p.tile_count == 0) return;
-    if (p.in_stride == 12u)
-        hipLaunchKernelGGL(bin_tile_kernel<false>, dim3(p.tile_count), dim3(kTileThreads), (size_t)(5 * p.PB + p.S + 1) * 4, s, p);
-    else
-        hipLaunchKernelGGL(bin_tile_kernel<true>, dim3(p.tile_count), dim3(kTileThreads), (size_t)(5 * p.PB + p.S + 1) * 4, s, p);
+    const size_t lds = (size_t)(5 * p.PB + p.S + 1) * 4;
+    const dim3 g(p.tile_count), b(kTileThreads);
+    if (p.sensors.n > 0) {
+        if (p.in_stride == 12u) hipLaunchKernelGGL((bin_tile_kernel<false, true>), g, b, lds, s, p);
+        else                    hipLaunchKernelGGL((bin_tile_kernel<true, true>), g, b, lds, s, p);
+    } else {
+        if (p.in_stride == 12u) hipLaunchKernelGGL((bin_tile_kernel<false, false>), g, b, lds, s, p);
+        else                    hipLaunchKernelGGL((bin_tile_kernel<true, false>), g, b, lds, s, p);
+    }
 }
 void launch_scan(const DevParams& p, hipStream_t s)
 {

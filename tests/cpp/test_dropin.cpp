@@ -75,6 +75,26 @@ int main()
         for (size_t i = 0; i < r6.first.size(); ++i) assert(std::memcmp(&r6.first[i], &r7.first[i], 12) == 0);
     }
 
+    // fusion pre-step on the device == rotating / ego-filtering on the host and calling filterGroundPoints
+    {
+        std::vector<std::vector<Point3D>> clouds = {synthetic(4000, 21), synthetic(3000, 22), synthetic(2000, 23)};
+        std::vector<LidarConfig> cfgs = {{1, "/lidar_front", 0.0f, 2.5f}, {2, "/lidar_left", 120.0f, 2.5f}, {3, "/lidar_right", -120.0f, 2.5f}};
+        auto fusedPair = patchwork.fuseAndFilterGroundPoints(clouds, cfgs);
+        std::vector<Point3D> fused;
+        for (size_t k = 0; k < clouds.size(); ++k) {
+            float a = cfgs[k].rotation_angle * M_PI / 180.0f; const float c = std::cos(a), s = std::sin(a);
+            for (auto p : clouds[k]) {
+                if (std::abs(cfgs[k].rotation_angle) > 1e-6f) { const float x = p.x * c - p.y * s, y = p.x * s + p.y * c; p.x = x; p.y = y; }
+                if (!(std::sqrt(p.x * p.x + p.y * p.y) <= cfgs[k].ego_radius)) fused.push_back(p);
+            }
+        }
+        auto hostPair = patchwork.filterGroundPoints(fused);
+        assert(fusedPair.first.size() == hostPair.first.size() && fusedPair.second.size() == hostPair.second.size());
+        for (size_t i = 0; i < hostPair.first.size(); ++i) assert(std::memcmp(&fusedPair.first[i], &hostPair.first[i], 12) == 0);
+        for (size_t i = 0; i < hostPair.second.size(); ++i) assert(std::memcmp(&fusedPair.second[i], &hostPair.second[i], 12) == 0);
+        std::printf("fusion: %zu ground, %zu non-ground\n", fusedPair.first.size(), fusedPair.second.size());
+    }
+
     // empty input: both empty
     auto r5 = def.filterGroundPoints({});
     assert(r5.first.empty() && r5.second.empty());

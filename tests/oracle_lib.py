@@ -78,6 +78,8 @@ def lib():
         L.rpwo_filter_ground_points.restype = C.c_int
         L.rpwo_filter_ground_points.argtypes = [C.POINTER(OConfig), C.c_void_p, C.c_uint32, C.c_void_p,
                                                 C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_uint32)]
+        L.rpwo_fuse.restype = C.c_int
+        L.rpwo_fuse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
         L.rpwo_eig3.restype = C.c_int
         L.rpwo_eig3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpwo_fit_plane.restype = None
@@ -154,3 +156,15 @@ def tables(cfg: OConfig):
     b = np.empty(cfg.num_sectors + 1, np.float32)
     lib().rpwo_tables(C.byref(cfg), e.ctypes.data, b.ctypes.data)
     return e, b
+
+
+def fuse(clouds, rotation_deg, ego_radius):
+    """LidarFusion pre-step on a list of raw sensor clouds -> (fused xyz, index into the concatenated raw cloud)."""
+    raw = np.ascontiguousarray(np.concatenate(clouds, axis=0), dtype=np.float32)
+    off = np.zeros(len(clouds) + 1, np.uint32); off[1:] = np.cumsum([len(c) for c in clouds])
+    rot = np.ascontiguousarray(rotation_deg, dtype=np.float32); ego = np.ascontiguousarray(ego_radius, dtype=np.float32)
+    out = np.empty_like(raw); src = np.empty(len(raw), np.uint32); n = C.c_uint32(0)
+    rc = lib().rpwo_fuse(raw.ctypes.data, off.ctypes.data, len(clouds), rot.ctypes.data, ego.ctypes.data,
+                         out.ctypes.data, src.ctypes.data, C.byref(n))
+    assert rc == 0
+    return out[: n.value].copy(), src[: n.value].copy(), raw, off

@@ -146,7 +146,7 @@ def test_cpp_dropin_program(tmp_path):
     subprocess.check_call(["make", "-C", pkg, "-s", "librecursive_patchwork.so"])
     exe = str(tmp_path / "test_dropin")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(pkg, "cpp"), "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), "-o", exe,
+                           "-ffp-contract=off", os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), "-o", exe,
                            "-L", pkg, "-lrecursive_patchwork", "-lrpw_hip", f"-Wl,-rpath,{pkg}"])
     out = subprocess.check_output([exe], text=True, timeout=300)
     assert "drop-in OK" in out
@@ -244,3 +244,60 @@ def test_pointcloud2_records_read_in_place(engine_factory):
             assert s[k] == want_s[k]
     with pytest.raises(rpw_amd.RpwError):
         eng.segment_pointcloud2(np.zeros(64, np.uint8), 4, 16, 0, 4, 14)      # misaligned field
+
+
+def _fusion_case(rs, kind):
+    if kind == 0:      # IAC-style: three sensors, 0 / +120 / -120 degrees (reference lidar_fusion.cpp:20-36)
+        clouds = [W.c2_hdl64(s)[:: 3 + s] for s in (11, 12, 13)]
+        return clouds, [0.0, 120.0, -120.0], [2.5, 2.5, 2.5]
+    if kind == 1:      # no rotation at all, different ego radii, a few non-finite points
+        clouds = [W.c1_test_cloud(31, n=8000), W.c1_test_cloud(32, n=3000)]
+        clouds[1][7] = np.nan; clouds[0][100, 1] = np.inf
+        return clouds, [0.0, 1e-7], [4.0, 0.0]
+    if kind == 2:      # one sensor, odd angle, big ego radius
+        return [W.c4_iac_fused(3, rays_per_sensor=30000)], [33.3], [6.0]
+    clouds = [W.c1_test_cloud(40 + k, n=int(rs.randint(1, 4000))) for k in range(8)]
+    clouds[3] = clouds[3][:0]            # an empty sensor cloud
+    return clouds, list(rs.uniform(-180, 180, 8)), list(rs.uniform(0, 8, 8))
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_lidar_fusion_prestep_on_device(engine_factory, kind):
+    """LidarFusion pre-step (rotation + ego-radius removal + concatenation) fused into the binning kernel:
+    labels of the surviving points == oracle run on the oracle-fused cloud; removed points carry LABEL_EGO."""
+    rs = np.random.RandomState(77 + kind)
+    clouds, rot, ego = _fusion_case(rs, kind)
+    fused, src, raw, off = O.fuse(clouds, rot, ego)
+    pc, oc = cfg_pair(max_split_depth=3, max_iter=6 if kind == 0 else 100, th_dist=0.05 if kind == 0 else 0.2)
+    eng = engine_factory(pc, max_points=len(raw) + 8, max_frames=2)
+    eng.set_sensors(rot, ego)
+    eng.set_trace(True, 1 << 17)
+    labels, res, st = eng.segment_fused(clouds, want_residual=True)
+    removed = np.ones(len(raw), bool); removed[src] = False
+    assert np.all(labels[removed] == rpw_amd.LABEL_EGO) and not np.any(labels[src] == rpw_amd.LABEL_EGO)
+    assert np.all(res[removed] == -1)
+    assert_frame_parity(fused, labels[src], res[src], st, eng.nodes(1 << 17), oc, tag=f"fusion kind {kind}")
+    # the plain call still works on the same handle, and so does switching the pre-step off
+    l2, _, s2 = eng.segment(fused)
+    assert np.array_equal(l2, labels[src]) and s2["n_ground"] == st["n_ground"]
+    if kind == 0:      # device-resident batch of two fused frames
+        import torch
+        frames = [raw, raw[::-1].copy()]
+        foff = np.array([0, len(raw), 2 * len(raw)], np.uint32)
+        so = np.stack([off, np.array([0, len(raw) - off[2], len(raw) - off[1], len(raw)], np.uint32)])
+        eng2 = engine_factory(pc, max_points=2 * len(raw), max_frames=2)
+        eng2.set_sensors([0.0, 120.0, -120.0], ego)
+        d = torch.from_numpy(np.concatenate(frames)).cuda()
+        lab = torch.empty(2 * len(raw), dtype=torch.uint8, device="cuda")
+        eng2.segment_batch_device_fused(d.data_ptr(), foff, so, lab.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        L = lab.cpu().numpy()
+        assert np.array_equal(L[: len(raw)], labels)
+        # frame 1: the reversed cloud, sensors in reversed sizes (rotations 0 / 120 / -120 applied to its three parts)
+        parts = [frames[1][so[1][k]: so[1][k + 1]] for k in range(3)]
+        f1, src1, _, _ = O.fuse(parts, [0.0, 120.0, -120.0], ego)
+        ref1 = O.segment(f1, oc, want_nodes=False)
+        assert np.array_equal(L[len(raw):][src1], ref1.labels)
+    eng.set_sensors([], [])
+    l3, _, _ = eng.segment(raw)
+    assert np.array_equal(l3, O.segment(raw, oc, want_nodes=False).labels)
