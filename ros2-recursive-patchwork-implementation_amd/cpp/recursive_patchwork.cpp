@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 #include <iostream>
+#include <random>
 #include <stdexcept>
 
 #include "rpw.h"
@@ -72,6 +73,49 @@ std::vector<Point3D> RecursivePatchwork::cleanPoints(const std::vector<Point3D>&
         if (std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z)) out.push_back(p);
     if (out.size() < points.size())
         std::cout << "Removed " << (points.size() - out.size()) << " points with NaN/inf values" << std::endl;
+    return out;
+}
+
+std::vector<Point3D> RecursivePatchwork::rotatePoints2D(const std::vector<Point3D>& points, float angle_degrees)
+{
+    // recursive_patchwork.cpp:37-54: float radians from a double product, cosf / sinf, two products and a difference / sum
+    float angle_rad = angle_degrees * M_PI / 180.0f;
+    const float cos_a = std::cos(angle_rad), sin_a = std::sin(angle_rad);
+    std::vector<Point3D> out; out.reserve(points.size());
+    for (const Point3D& p : points) out.emplace_back(p.x * cos_a - p.y * sin_a, p.x * sin_a + p.y * cos_a, p.z);
+    return out;
+}
+
+std::vector<Point3D> RecursivePatchwork::sampleGroundAndObstacles(const std::vector<Point3D>& points,
+                                                                  float target_height, float base_tol)
+{
+    auto parts = filterGroundPoints(points);
+    std::vector<Point3D>& ground = parts.first;
+    std::vector<Point3D>& non_ground = parts.second;
+    if (non_ground.empty()) return ground;
+    std::vector<Point3D> obstacles; obstacles.reserve(non_ground.size());
+    for (const Point3D& p : non_ground) {
+        if (!(std::sqrt(p.x * p.x + p.y * p.y) > 2.5f)) continue;                 // removeEgoVehicle(non_ground, 2.5f)
+        if (std::abs(p.z - target_height) <= base_tol) obstacles.push_back(p);
+    }
+    std::vector<Point3D> sample;
+    if (!ground.empty()) {
+        const size_t want = std::min<size_t>(2000, ground.size());
+        if (ground.size() <= want) sample = ground;
+        else {                                                                   // draw without replacement, rejection as in randomSubsample
+            std::mt19937 gen(have_sample_seed_ ? sample_seed_ : std::random_device{}());
+            std::uniform_int_distribution<size_t> pick(0, ground.size() - 1);
+            std::vector<bool> taken(ground.size(), false);
+            sample.reserve(want);
+            while (sample.size() < want) {
+                const size_t i = pick(gen);
+                if (!taken[i]) { taken[i] = true; sample.push_back(ground[i]); }
+            }
+        }
+    }
+    std::vector<Point3D> out; out.reserve(sample.size() + obstacles.size());
+    out.insert(out.end(), sample.begin(), sample.end());
+    out.insert(out.end(), obstacles.begin(), obstacles.end());
     return out;
 }
 

@@ -74,7 +74,16 @@ public:
     fuseAndFilterGroundPoints(const std::vector<std::vector<Point3D>>& lidar_point_clouds,
                               const std::vector<LidarConfig>& lidar_configs);
 
+    // Post-step of the reference (recursive_patchwork.cpp:428-465): filterGroundPoints, then on the host: ego-radius
+    // removal (2.5 m) of the non-ground points, height band |z - target_height| <= base_tol, plus up to 2000 ground
+    // points drawn without replacement. The reference seeds that draw from std::random_device; so does this class
+    // unless setSampleSeed() was called (reproducible runs and tests).
+    std::vector<Point3D> sampleGroundAndObstacles(const std::vector<Point3D>& points,
+                                                  float target_height = 1.1f, float base_tol = 0.5f);
+    void setSampleSeed(unsigned seed) { sample_seed_ = seed; have_sample_seed_ = true; }
+
     std::vector<Point3D> cleanPoints(const std::vector<Point3D>& points);
+    std::vector<Point3D> rotatePoints2D(const std::vector<Point3D>& points, float angle_degrees);
 
     void setConfig(const PatchworkConfig& config);
     const PatchworkConfig& getConfig() const { return config_; }
@@ -89,6 +98,8 @@ private:
     size_t capacity_ = 0;
     int device_ = 0;
     unsigned n_zone_last_ = 0;
+    unsigned sample_seed_ = 0;
+    bool have_sample_seed_ = false;
 };
 
 // same utility as the reference (recursive_patchwork.hpp:90-105)

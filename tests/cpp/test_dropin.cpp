@@ -6,6 +6,7 @@
 #include <cassert>
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <random>
 #include <vector>
@@ -93,6 +94,25 @@ int main()
         for (size_t i = 0; i < hostPair.first.size(); ++i) assert(std::memcmp(&fusedPair.first[i], &hostPair.first[i], 12) == 0);
         for (size_t i = 0; i < hostPair.second.size(); ++i) assert(std::memcmp(&fusedPair.second[i], &hostPair.second[i], 12) == 0);
         std::printf("fusion: %zu ground, %zu non-ground\n", fusedPair.first.size(), fusedPair.second.size());
+    }
+
+    // sampleGroundAndObstacles (reference test: testEnhancedFiltering) and rotatePoints2D
+    {
+        auto pts = synthetic(30000, 5);
+        RecursivePatchwork pw;
+        pw.setSampleSeed(7);
+        auto parts = pw.filterGroundPoints(pts);
+        auto s1 = pw.sampleGroundAndObstacles(pts, 1.1f, 0.5f);
+        auto s2 = pw.sampleGroundAndObstacles(pts, 1.1f, 0.5f);
+        assert(s1.size() == s2.size() && s1.size() > 0 && s1.size() <= pts.size());
+        for (size_t i = 0; i < s1.size(); ++i) assert(std::memcmp(&s1[i], &s2[i], 12) == 0);     // seeded => reproducible
+        size_t n_obs = 0;
+        for (const auto& p : parts.second) if (std::sqrt(p.x * p.x + p.y * p.y) > 2.5f && std::abs(p.z - 1.1f) <= 0.5f) ++n_obs;
+        const size_t n_ground_sample = std::min<size_t>(2000, parts.first.size());
+        assert(s1.size() == n_ground_sample + n_obs);
+        for (size_t i = n_ground_sample; i < s1.size(); ++i) assert(std::abs(s1[i].z - 1.1f) <= 0.5f);
+        auto rot = pw.rotatePoints2D({{1.f, 0.f, 3.f}}, 90.0f);
+        assert(std::abs(rot[0].x) < 1e-6f && std::abs(rot[0].y - 1.f) < 1e-6f && rot[0].z == 3.f);
     }
 
     // empty input: both empty
