@@ -301,3 +301,19 @@ def test_lidar_fusion_prestep_on_device(engine_factory, kind):
     eng.set_sensors([], [])
     l3, _, _ = eng.segment(raw)
     assert np.array_equal(l3, O.segment(raw, oc, want_nodes=False).labels)
+
+
+def test_huge_frame_and_huge_patches(engine_factory):
+    """A 2.3 M-point frame (more tiles than the gather keeps in LDS: global binary-search fallback) cut into few,
+    very large patches (num_sectors = 2 -> 16 patches, the largest > 300 k points)."""
+    a = W.c5_dense(0)
+    ang = np.float32(0.7); c, s = np.float32(np.cos(ang)), np.float32(np.sin(ang))
+    b = np.column_stack([a[:, 0] * c - a[:, 1] * s, a[:, 0] * s + a[:, 1] * c, a[:, 2] + np.float32(0.01)]).astype(np.float32)
+    xyz = np.concatenate([a, b, a[:200000] * np.float32(0.5)])
+    assert len(xyz) > 1024 * 2048
+    pc, oc = cfg_pair(num_sectors=2, max_iter=8, max_split_depth=2, th_dist=0.1)
+    eng = engine_factory(pc, max_points=len(xyz), max_frames=1)
+    eng.set_trace(True, 1 << 16)
+    labels, res, st = eng.segment(xyz, want_residual=True)
+    ref = assert_frame_parity(xyz, labels, res, st, eng.nodes(1 << 16), oc, tag="huge")
+    assert ref.nodes["len"].max() > 300000
