@@ -162,7 +162,8 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
         cls[r] = valid ? c : p.P;
         loff[r] = 0;
         if (valid) {
-            p.labels[fo + i] = (uint8_t)(c <= p.P ? RPW_LABEL_NONGROUND : (c == p.P + 1 ? RPW_LABEL_OUTSIDE : (c == p.P + 2 ? RPW_LABEL_DROPPED : RPW_LABEL_EGO)));
+            // points of a patch get their label (0 or 1) from patch_fit; only the special classes are labelled here
+            if (c >= p.P) p.labels[fo + i] = (uint8_t)(c == p.P ? RPW_LABEL_NONGROUND : (c == p.P + 1 ? RPW_LABEL_OUTSIDE : (c == p.P + 2 ? RPW_LABEL_DROPPED : RPW_LABEL_EGO)));
             if (p.residual) p.residual[fo + i] = -1.0f;
         }
         // stable rank inside the wave's sub-tile: one step per distinct class of the row
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
             p.patch_begin[(size_t)f * (p.P + 1) + c] = begin;
             PatchDesc d; d.begin = fo + begin; d.n = v;
             p.patches[(size_t)f * p.P + c] = d;
-            if (v > 0 && !zone_too_small) {
+            if (v > 0) {                                   // (also when zone < 3: patch_fit then only writes label 0)
                 const int b = size_bucket(v);
                 const uint32_t pos = atomicAdd(&p.bucket_count[b], 1u);
                 p.bucket_list[(size_t)b * p.list_stride + pos] = f * (uint32_t)p.P + (uint32_t)c;
@@ -740,6 +741,12 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
         __syncthreads();
     }
 
+    // zone < 3: the reference returns {{}, cleaned} before looking at any patch (recursive_patchwork.cpp:339-341)
+    if (p.stats[frame].n_zone < 3u) {
+        for (uint32_t i = tid; i < pd.n; i += kFitThreads) p.labels[fo + p.sidx[pd.begin + i]] = RPW_LABEL_NONGROUND;
+        return;
+    }
+
     // ---- mean distance of the patch (recursive_patchwork.cpp:383-387): sequential sum of d ------
     float mean_dist;
     {
@@ -797,10 +804,9 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
             else if ((zmx - zmn) < 0.05f && n > 10) leaf_kind = RPW_NODE_FLAT;
         }
         if (leaf_kind >= 0) {
-            if (leaf_kind != RPW_NODE_REJECT) {
-                for (uint32_t i = tid; i < n; i += kFitThreads) p.labels[fo + gi[i]] = RPW_LABEL_GROUND;
-                pa.ground += n;
-            }
+            const uint8_t lab = leaf_kind == RPW_NODE_REJECT ? RPW_LABEL_NONGROUND : RPW_LABEL_GROUND;
+            for (uint32_t i = tid; i < n; i += kFitThreads) p.labels[fo + gi[i]] = lab;
+            if (leaf_kind != RPW_NODE_REJECT) pa.ground += n;
             emit_node(p, tid, frame, patch, depth, s, n, leaf_kind, 0, leaf_kind == RPW_NODE_REJECT ? 0u : n, -1, 0.0f, nullptr);
             continue;
         }
@@ -972,7 +978,7 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
         pa.iters += (unsigned long long)iters;
         for (uint32_t i = tid; i < n; i += kFitThreads) {
             const uint32_t orig = gi[i];
-            if ((gm[i] >> final_bit) & 1u) p.labels[fo + orig] = RPW_LABEL_GROUND;
+            p.labels[fo + orig] = ((gm[i] >> final_bit) & 1u) ? RPW_LABEL_GROUND : RPW_LABEL_NONGROUND;
             if (p.residual) {
                 float x, y, z;
                 if (permuted) {
