@@ -51,7 +51,7 @@ struct rpw_handle {
     uint32_t max_tiles = 0;
     uint32_t* d_patch_begin = nullptr;
     PatchDesc* d_patches = nullptr;
-    uint32_t* d_ctrl = nullptr;          // [kBuckets] bucket counts + [1] node count (+pad)
+    uint32_t* d_ctrl = nullptr;          // [kBuckets] bucket counts + [1] node count (+pad), then [F][PB] class totals of every frame
     uint32_t* d_bucket_list = nullptr;
     float *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr, *d_ax = nullptr, *d_ay = nullptr, *d_az = nullptr;
     float4* d_tp = nullptr;
@@ -186,7 +186,7 @@ rpw_status allocate(rpw_handle* h)
     RPW_HIP(h, hipMalloc(&h->d_hist, (size_t)h->max_tiles * h->PB * sizeof(uint32_t)));
     RPW_HIP(h, hipMalloc(&h->d_patch_begin, F * (size_t)(h->P + 1) * sizeof(uint32_t)));
     RPW_HIP(h, hipMalloc(&h->d_patches, F * (size_t)h->P * sizeof(PatchDesc)));
-    RPW_HIP(h, hipMalloc(&h->d_ctrl, (kBuckets + 4) * sizeof(uint32_t)));
+    RPW_HIP(h, hipMalloc(&h->d_ctrl, (kBuckets + 4 + F * (size_t)h->PB) * sizeof(uint32_t)));     // + per-frame class totals
     RPW_HIP(h, hipMalloc(&h->d_bucket_list, (size_t)kBuckets * F * h->P * sizeof(uint32_t)));
     RPW_HIP(h, hipMalloc(&h->d_sx, N * sizeof(float)));
     RPW_HIP(h, hipMalloc(&h->d_sy, N * sizeof(float)));
@@ -282,7 +282,7 @@ rpw_status run_batch(rpw_handle* h, const void* d_xyz, const uint32_t* frame_off
     RPW_HIP(h, hipMemcpyAsync(h->d_offsets, ho, copy_words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     RPW_HIP(h, hipEventRecord(h->stage_ev[slot], stream));
     h->stage_used[slot] = true;
-    RPW_HIP(h, hipMemsetAsync(h->d_ctrl, 0, (kBuckets + 4) * sizeof(uint32_t), stream));
+    RPW_HIP(h, hipMemsetAsync(h->d_ctrl, 0, (kBuckets + 4 + (size_t)F * h->PB) * sizeof(uint32_t), stream));
 
     DevParams p;
     p.cfg = h->cfg; p.tab = h->tab; p.bounds = h->d_bounds; p.S = h->S; p.P = h->P; p.PB = h->PB;
@@ -291,7 +291,7 @@ rpw_status run_batch(rpw_handle* h, const void* d_xyz, const uint32_t* frame_off
     p.in_off[0] = lay.off[0]; p.in_off[1] = lay.off[1]; p.in_off[2] = lay.off[2]; p.labels = d_labels;
     p.sensors = h->sensors; if (ns == 0) p.sensors.n = 0;
     p.sensor_off = h->d_offsets + 2 * (F + 1); p.residual = d_residual;
-    p.hist = h->d_hist; p.patch_begin = h->d_patch_begin; p.patches = h->d_patches;
+    p.hist = h->d_hist; p.ftot = h->d_ctrl + kBuckets + 4; p.patch_begin = h->d_patch_begin; p.patches = h->d_patches;
     p.bucket_count = h->d_ctrl; p.bucket_list = h->d_bucket_list; p.list_stride = h->max_frames * (uint32_t)h->P;
     p.tp = h->d_tp; p.tdir = h->d_tdir;
     p.sx = h->d_sx; p.sy = h->d_sy; p.sz = h->d_sz; p.sidx = h->d_sidx; p.ax = h->d_ax; p.ay = h->d_ay; p.az = h->d_az;

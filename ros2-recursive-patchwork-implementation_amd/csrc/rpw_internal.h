@@ -16,6 +16,7 @@ constexpr int kWavePoints  = kWave * kTileItems;  // 512: one wave owns a contig
 constexpr int kMaxSectors  = 128;
 constexpr int kMaxSensors  = 8;                   // LidarFusion pre-step: sensors per frame
 constexpr int kBuckets     = 64;                  // patch-size buckets for largest-first launch order
+constexpr int kGatherTiles = 1024;                // frames of up to 2.1 M points: patch_fit scans its run directory in LDS
 constexpr int kStackDepth  = 48;                  // explicit recursion stack (smaller child first => <= log2(n)+2)
 
 struct PatchDesc {
@@ -55,7 +56,9 @@ struct DevParams {
     uint8_t*  labels;
     float*    residual;           // may be null
 
-    uint32_t* hist;               // [n_tiles][PB]: counts, then (after scan) frame-relative offsets
+    uint32_t* hist;               // [n_tiles][PB]: run length of every class inside the tile (frames of more than
+                                  // kGatherTiles tiles: turned into frame-relative offsets by scan_offsets)
+    uint32_t* ftot;               // [F][PB] points of every class in the frame (bin_tile adds its tile's counts; zeroed per batch)
     uint32_t* patch_begin;        // [F][P+1], frame-relative
     PatchDesc* patches;           // [F*P]
     uint32_t* bucket_count;       // [kBuckets]

@@ -119,7 +119,7 @@ template <bool STRIDED, bool FUSED>
 __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
 {
     extern __shared__ uint32_t lds_u32[];
-    volatile uint32_t* wcnt = lds_u32;                            // [4][PB] per-wave running counts, then wave offsets
+    uint32_t* wcnt = lds_u32;                                     // [4][PB] per-wave running counts, then wave offsets
     uint32_t* tstart = lds_u32 + 4 * p.PB;                        // [PB] class totals, then run starts inside the tile
     float* bnd = reinterpret_cast<float*>(lds_u32 + 5 * p.PB);    // [S+1] sector bounds
     __shared__ uint32_t red[8];
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
     const uint32_t nf = p.frame_off[f + 1] - fo;
     const uint32_t t_local = tile - p.tile_base[f];
     const uint32_t wbase = t_local * kTilePoints + wave * kWavePoints;
-    volatile uint32_t* mycnt = wcnt + wave * p.PB;
+    uint32_t* mycnt = wcnt + wave * p.PB;
 
     // all of the wave's loads first (8 x 12 B per lane in flight), then the arithmetic
     P3 q[kTileItems];
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
         unsigned long long rem = ballot64(valid);
         while (rem) {
             const int first = __ffsll((long long)rem) - 1;
-            const int c0 = __shfl(cls[r], first);
+            const int c0 = __builtin_amdgcn_readlane(cls[r], first);      // `first` is wave-uniform: no LDS round trip
             const unsigned long long m = ballot64(valid && cls[r] == c0);
             const uint32_t old = mycnt[c0];
             if (valid && cls[r] == c0) loff[r] = old + (uint32_t)mbcnt64(m);
@@ -188,16 +188,24 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
     __syncthreads();
     uint32_t* hist_out = p.hist + (size_t)tile * p.PB;
     uint32_t* tdir_out = p.tdir + (size_t)tile * p.PB;
+    uint32_t* ftot = p.ftot + (size_t)f * p.PB;                     // class totals of the frame (integer adds: order-free)
     uint32_t running = 0;
     for (int c0 = 0; c0 < p.P; c0 += kTileThreads) {              // exclusive prefix over the patch classes
         const int c = c0 + tid;
         const uint32_t v = c < p.P ? tstart[c] : 0u;
         uint32_t total;
         const uint32_t ex = block_excl_scan(v, red, total);
-        if (c < p.P) { hist_out[c] = v; tdir_out[c] = running + ex; tstart[c] = running + ex; }
+        if (c < p.P) {
+            hist_out[c] = v; tdir_out[c] = running + ex; tstart[c] = running + ex;
+            if (v) atomicAdd(&ftot[c], v);                           // a tile of scan-ordered points touches a few classes only
+        }
         running += total;
     }
-    if (tid < 4) hist_out[p.P + tid] = tstart[p.P + tid];          // special classes: totals only
+    if (tid < 4) {                                                  // special classes: totals only
+        const uint32_t v = tstart[p.P + tid];
+        hist_out[p.P + tid] = v;
+        if (v) atomicAdd(&ftot[p.P + tid], v);
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kTileItems; ++r) {
@@ -239,9 +247,10 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* r
 
 __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
 {
-    // One block per frame. Class c (patch ids, then the 3 special classes) is walked by `parts` threads,
-    // each over a contiguous range of tiles; every load address is known up front, so the walks
-    // pipeline instead of paying one L2 round trip per step.
+    // One block per frame. The class totals of the frame are there already (bin_tile added them up), so the
+    // usual frame needs one scan over the classes and nothing else. Only a frame of more than kGatherTiles
+    // tiles has its run lengths turned into offsets here (patch_fit cannot hold its run directory in LDS then):
+    // class c is walked by `parts` threads, each over a contiguous range of tiles.
     extern __shared__ uint32_t lds_u32[];
     const int C = p.P + 4;
     int parts = kScanThreads / C; if (parts > 16) parts = 16; if (parts < 1) parts = 1;
@@ -256,20 +265,23 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
     const uint32_t nf = p.frame_off[f + 1] - fo;
     uint32_t* base = p.hist + (size_t)t0 * p.PB;
     const uint32_t per = (nt + parts - 1) / parts;
+    const bool big = nt > (uint32_t)kGatherTiles;
 
-    for (int w = tid; w < C * parts; w += kScanThreads) {
-        const int c = w % C, pt = w / C;
-        const uint32_t ta = pt * per, tb = ta + per < nt ? ta + per : nt;
-        uint32_t acc = 0;
+    for (int c = tid; c < C; c += kScanThreads) tot[c] = p.ftot[(size_t)f * p.PB + c];
+    if (big) {
+        for (int w = tid; w < C * parts; w += kScanThreads) {
+            const int c = w % C, pt = w / C;
+            const uint32_t ta = pt * per, tb = ta + per < nt ? ta + per : nt;
+            uint32_t acc = 0;
 #pragma unroll 8
-        for (uint32_t t = ta; t < tb; ++t) acc += base[(size_t)t * p.PB + c];
-        part[pt * p.PB + c] = acc;
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += kScanThreads) {
-        uint32_t s = 0;
-        for (int pt = 0; pt < parts; ++pt) { const uint32_t v = part[pt * p.PB + c]; part[pt * p.PB + c] = s; s += v; }
-        tot[c] = s;
+            for (uint32_t t = ta; t < tb; ++t) acc += base[(size_t)t * p.PB + c];
+            part[pt * p.PB + c] = acc;
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += kScanThreads) {
+            uint32_t s = 0;
+            for (int pt = 0; pt < parts; ++pt) { const uint32_t v = part[pt * p.PB + c]; part[pt * p.PB + c] = s; s += v; }
+        }
     }
     __syncthreads();
     // zone < 3: the reference returns {{}, cleaned} before looking at any patch (recursive_patchwork.cpp:339-341)
@@ -298,8 +310,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
         running += total; npatches += nz_total;
     }
     __syncthreads();
-    // running offsets per class over the tiles, in tile (= input) order
-    for (int w = tid; w < p.P * parts; w += kScanThreads) {
+    // big frames only: running offsets per class over the tiles, in tile (= input) order
+    if (big) for (int w = tid; w < p.P * parts; w += kScanThreads) {
         const int c = w % p.P, pt = w / p.P;
         const uint32_t ta = pt * per, tb = ta + per < nt ? ta + per : nt;
         uint32_t off = tot[c] + part[pt * p.PB + c];
@@ -335,7 +347,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
 // order statistics, stable partition, labels).
 // ------------------------------------------------------------------------------------------
 constexpr int kFitThreads = 128;
-constexpr int kGatherTiles = 1024;     // frames up to 2.1 M points keep the gather's two directory columns in LDS
 constexpr int kLdw  = 68;              // ring row stride in floats: 64 + 4 keeps the 6 chain lanes on distinct banks
 constexpr int kRing = 8;               // ring slots of 64 addends; the producer writes at most 3 slots past the last rendezvous
 constexpr int kSlotFloats = 6 * kLdw;
@@ -696,23 +707,37 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
     uint32_t* stk = sh.stk;
 
     // ---- gather: assemble the patch's contiguous slots from its runs in the tile-sorted arrays ------------
-    // Run (tile t, this patch) lives at tile-slot tdir[t][patch] of tile t and goes to frame-relative slot
-    // hist[t][patch] (K2 turned the run lengths into destination offsets). Destination slot d belongs to the
-    // LAST tile whose offset is <= d (empty runs repeat an offset). Input order is kept: runs in tile order.
+    // Run (tile t, this patch) lives at tile-slot tdir[t][patch] of tile t, is hist[t][patch] points long and goes
+    // to the patch slots that follow the runs of the earlier tiles (exclusive prefix over the tiles, made here).
+    // Destination slot d belongs to the LAST tile whose offset is <= d (empty runs repeat an offset). Input order
+    // is kept: runs in tile order.
     {
         const uint32_t t0 = p.tile_base[frame];
         const uint32_t nt = p.tile_base[frame + 1] - t0;
         const bool in_lds = nt <= (uint32_t)kGatherTiles;
         uint32_t* toff = sh.toff;                                       // destination offset of the run, per tile
         uint32_t* tsrc = sh.tsrc;                                       // frame-relative source slot of the run, per tile
-        const uint32_t* goff = p.hist + (size_t)t0 * p.PB + patch;      // stride PB
+        const uint32_t* goff = p.hist + (size_t)t0 * p.PB + patch;      // stride PB: run lengths (offsets for a big frame)
         const uint32_t* gdir = p.tdir + (size_t)t0 * p.PB + patch;      // stride PB
-        if (in_lds) for (uint32_t t = tid; t < nt; t += kFitThreads) {
-            toff[t] = goff[(size_t)t * p.PB];
-            tsrc[t] = t * kTilePoints + gdir[(size_t)t * p.PB];
+        if (in_lds) {
+            // this patch's run length in every tile -> exclusive prefix = destination offset inside the patch;
+            // thread i owns tiles [i*per, (i+1)*per)
+            const uint32_t per = (nt + kFitThreads - 1) / kFitThreads;
+            const uint32_t ta = (uint32_t)tid * per, tb = ta + per < nt ? ta + per : nt;
+            uint32_t sum = 0;
+            for (uint32_t t = ta; t < tb; ++t) {
+                const uint32_t len = goff[(size_t)t * p.PB];
+                toff[t] = len; sum += len;
+                tsrc[t] = t * kTilePoints + gdir[(size_t)t * p.PB];
+            }
+            const uint32_t incl = wave_incl_scan(sum);
+            if (lane == 63) sh.red[wave][0] = incl;
+            __syncthreads();
+            uint32_t run = incl - sum + (wave == 1 ? sh.red[0][0] : 0u);
+            for (uint32_t t = ta; t < tb; ++t) { const uint32_t len = toff[t]; toff[t] = run; run += len; }
         }
         __syncthreads();
-        const uint32_t rel0 = pd.begin - fo;
+        const uint32_t rel0 = in_lds ? 0u : pd.begin - fo;              // LDS offsets are patch-relative, global ones frame-relative
         auto source_of = [&](uint32_t j) -> uint32_t {                  // tile-sorted slot that feeds patch slot j
             const uint32_t d = rel0 + j;
             uint32_t lo = 0, hi = nt;
