@@ -163,6 +163,12 @@ void build_tables(const rpw_config& c, PolarTables& t, std::vector<float>& bound
     }
     t.gt_radius = min_s_with_sqrt_gt(c.filtering_radius);
     t.inv_sector = 1.0f / sector_angle;
+    {   // cheap angle in sector units (approximate path: plain float arithmetic is fine here)
+        const float coef[5] = {0.9998660f, -0.3302995f, 0.1801410f, -0.0851330f, 0.0208351f};
+        for (int i = 0; i < 5; ++i) t.ac[i] = coef[i] * t.inv_sector;
+        t.uq = 0.25f * (float)c.num_sectors; t.uh = 0.5f * (float)c.num_sectors; t.uf = (float)c.num_sectors;
+        t.usure = 0.5f - 1.0e-4f * t.inv_sector;
+    }
     bounds.resize((size_t)c.num_sectors + 1);
     for (int k = 0; k <= c.num_sectors; ++k) bounds[k] = k * sector_angle;
 }
@@ -279,6 +285,9 @@ rpw_status run_batch(rpw_handle* h, const void* d_xyz, const uint32_t* frame_off
         copy_words += (size_t)F * (ns + 1);
     }
     if (tiles > h->max_tiles) return fail(h, RPW_ERR_CAPACITY, "tile count %u > capacity %u", tiles, h->max_tiles);
+    for (uint32_t f = 0; f < F; ++f)      // bin_tile addresses a frame's records with 32-bit byte offsets
+        if ((uint64_t)(frame_offsets[f + 1] - frame_offsets[f]) * 16u > 0xffffffffull)
+            return fail(h, RPW_ERR_CAPACITY, "frame %u has %u points; the limit is 268435455 per frame", f, frame_offsets[f + 1] - frame_offsets[f]);
     RPW_HIP(h, hipMemcpyAsync(h->d_offsets, ho, copy_words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     RPW_HIP(h, hipEventRecord(h->stage_ev[slot], stream));
     h->stage_used[slot] = true;

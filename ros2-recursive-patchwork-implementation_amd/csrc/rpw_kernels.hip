@@ -137,12 +137,14 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
     uint32_t* mycnt = wcnt + wave * p.PB;
 
     // all of the wave's loads first (8 x 12 B per lane in flight), then the arithmetic
+    const char* frame_bytes = reinterpret_cast<const char*>(p.xyz + fo);      // frames are < 4 GB (rpw_create checks)
     P3 q[kTileItems];
 #pragma unroll
     for (int r = 0; r < kTileItems; ++r) {
         const uint32_t i = wbase + r * kWave + lane;
         q[r].x = q[r].y = q[r].z = 1.0f;
-        if (i < nf) q[r] = STRIDED ? load_point(p, fo + i) : p.xyz[fo + i];     // packed: one dwordx3 load
+        // packed: one dwordx3 load, uniform frame base + 32-bit byte offset (no 64-bit address arithmetic per lane)
+        if (i < nf) q[r] = STRIDED ? load_point(p, fo + i) : *reinterpret_cast<const P3*>(frame_bytes + i * 12u);
     }
     int cls[kTileItems];
     uint32_t loff[kTileItems];
@@ -196,7 +198,10 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
         uint32_t total;
         const uint32_t ex = block_excl_scan(v, red, total);
         if (c < p.P) {
-            hist_out[c] = v; tdir_out[c] = running + ex; tstart[c] = running + ex;
+            const uint32_t start = running + ex;
+            hist_out[c] = v; tdir_out[c] = start;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) wcnt[w * p.PB + c] += start;  // run start + the wave's offset inside the run
             if (v) atomicAdd(&ftot[c], v);                           // a tile of scan-ordered points touches a few classes only
         }
         running += total;
@@ -207,12 +212,13 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
         if (v) atomicAdd(&ftot[p.P + tid], v);
     }
     __syncthreads();
+    char* tile_bytes = reinterpret_cast<char*>(p.tp + fo + t_local * kTilePoints);
 #pragma unroll
     for (int r = 0; r < kTileItems; ++r) {
         const uint32_t i = wbase + r * kWave + lane;
         if (i < nf && cls[r] < p.P) {
-            const uint32_t slot = fo + t_local * kTilePoints + tstart[cls[r]] + mycnt[cls[r]] + loff[r];
-            p.tp[slot] = make_float4(q[r].x, q[r].y, q[r].z, __uint_as_float(i));     // one 16-byte store
+            const uint32_t slot = mycnt[cls[r]] + loff[r];                            // inside the tile's region
+            *reinterpret_cast<float4*>(tile_bytes + slot * 16u) = make_float4(q[r].x, q[r].y, q[r].z, __uint_as_float(i));   // one 16-byte store
         }
     }
 }

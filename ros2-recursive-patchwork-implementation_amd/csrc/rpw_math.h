@@ -345,8 +345,22 @@ struct PolarTables {
     float inv_sector;        // 1 / sector_angle, only a search hint
     int   num_sectors;
     int   edges_monotone;    // edges non-decreasing (always, unless filtering_radius < 1)
+    // cheap angle in SECTOR UNITS (angle / sector_angle): odd degree-9 polynomial of min/max, coefficients
+    // premultiplied by inv_sector; quarter / half / full turn in the same units; half-width of the sure band
+    float ac[5];
+    float uq, uh, uf;
+    float usure;             // a point is decided by the cheap angle iff |frac(u) - 0.5| < usure  (1e-4 rad from either bound)
     // sector bounds bounds[k] = (float)k * sector_angle live in a separate array (device memory / LDS)
 };
+
+RPW_HD float fract_(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fractf(x);
+#else
+    return x - __builtin_floorf(x);
+#endif
+}
 
 RPW_HD float fast_rcp(float x)
 {
@@ -390,22 +404,23 @@ RPW_HD int classify_point_fast(float x, float y, float z, const PolarTables& t, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) ring = (s >= t.ge[i] && s < t.ge[i + 1]) ? i : ring;
     }
-    // cheap angle in [0, 2pi]: |error| < 2e-5 (degree-9 odd polynomial on [0,1], 1-ulp reciprocal)
+    // cheap angle, in sector units u = angle / sector_angle in [0, S]: |error| < 2e-5 rad (degree-9 odd polynomial on
+    // [0,1], 1-ulp reciprocal). Sector = floor(u); the point is decided here only if u is farther than 1e-4 rad from
+    // both neighbouring integers (the reference's bounds[k] = k * sector_angle are within 2e-6 rad of them).
     const float ax = fabs_(x), ay = fabs_(y);
     const bool steep = ay > ax;
     const float mx = steep ? ay : ax, mn = steep ? ax : ay;
     const float q = mn * fast_rcp(mx);
     const float q2 = q * q;
     // this path is approximate by design, so fused multiply-adds are welcome here
-    float p = q * __builtin_fmaf(q2, __builtin_fmaf(q2, __builtin_fmaf(q2, __builtin_fmaf(q2, 0.0208351f, -0.0851330f), 0.1801410f), -0.3302995f), 0.9998660f);
-    p = steep ? 1.57079637f - p : p;
-    p = x < 0.0f ? 3.14159274f - p : p;
-    p = y < 0.0f ? 6.28318548f - p : p;
-    int k = (int)(p * t.inv_sector);
+    float u = q * __builtin_fmaf(q2, __builtin_fmaf(q2, __builtin_fmaf(q2, __builtin_fmaf(q2, t.ac[4], t.ac[3]), t.ac[2]), t.ac[1]), t.ac[0]);
+    u = steep ? t.uq - u : u;
+    u = x < 0.0f ? t.uh - u : u;
+    u = y < 0.0f ? t.uf - u : u;
+    int k = (int)u;
     k = k > S - 1 ? S - 1 : k;
     k = k < 0 ? 0 : k;                   // also maps a NaN angle (x = y = 0 or non-finite input) to 0
-    const float eps = 1.0e-4f;
-    const bool sure = (p - bounds[k]) > eps && (bounds[k + 1] - p) > eps;
+    const bool sure = fabs_(fract_(u) - 0.5f) < t.usure;      // false for NaN and for u >= S (then frac ~ 0)
     const bool inpatch = fin && inzone && ring >= 0;
     uncertain = inpatch && !sure;
     return !fin ? P + 2 : (!inzone ? P + 1 : ((ring < 0 || !sure) ? P : ring * S + k));
