@@ -261,8 +261,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
     const int C = p.P + 4;
     int parts = kScanThreads / C; if (parts > 16) parts = 16; if (parts < 1) parts = 1;
     uint32_t* tot = lds_u32;                  // [PB] per-class totals, then patch_begin
-    uint32_t* part = lds_u32 + p.PB;          // [parts][PB] partial totals, then exclusive prefix over parts
+    uint32_t* lrank = lds_u32 + p.PB;         // [PB] per patch: size bucket << 16 | rank inside the block's share of it
+    uint32_t* part = lds_u32 + 2 * p.PB;      // [parts][PB] partial totals, then exclusive prefix over parts (big frames)
     __shared__ uint32_t red[kScanThreads / 64];
+    __shared__ uint32_t bcount[kBuckets];
     const int tid = threadIdx.x;
     const uint32_t f = blockIdx.x + p.frame_first;
     const uint32_t t0 = p.tile_base[f];
@@ -293,8 +295,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
     // zone < 3: the reference returns {{}, cleaned} before looking at any patch (recursive_patchwork.cpp:339-341)
     const uint32_t n_dropped = tot[p.P + 2], n_outside = tot[p.P + 1], n_ego = tot[p.P + 3];
     const bool zone_too_small = (nf - n_ego - n_dropped - n_outside) < 3u;
-    // exclusive prefix over the patch classes, block-wide
+    // exclusive prefix over the patch classes, block-wide. Bucket positions: the block first ranks its patches
+    // inside every size bucket in LDS, then reserves one range per bucket with a single global atomic (thousands of
+    // returning atomics on a handful of counters cost tens of microseconds; the order inside a bucket is free).
     uint32_t running = 0, npatches = 0;
+    for (int b = tid; b < kBuckets; b += kScanThreads) bcount[b] = 0;
+    __syncthreads();
     for (int c0 = 0; c0 < p.P; c0 += kScanThreads) {
         const int c = c0 + tid;
         const uint32_t v = c < p.P ? tot[c] : 0u;
@@ -307,15 +313,21 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
             p.patch_begin[(size_t)f * (p.P + 1) + c] = begin;
             PatchDesc d; d.begin = fo + begin; d.n = v;
             p.patches[(size_t)f * p.P + c] = d;
-            if (v > 0) {                                   // (also when zone < 3: patch_fit then only writes label 0)
-                const int b = size_bucket(v);
-                const uint32_t pos = atomicAdd(&p.bucket_count[b], 1u);
-                p.bucket_list[(size_t)b * p.list_stride + pos] = f * (uint32_t)p.P + (uint32_t)c;
-            }
+            // (also when zone < 3: patch_fit then only writes label 0)
+            lrank[c] = v > 0 ? ((uint32_t)size_bucket(v) << 16) | atomicAdd(&bcount[size_bucket(v)], 1u) : 0xffffffffu;
         }
         running += total; npatches += nz_total;
     }
     __syncthreads();
+    for (int b = tid; b < kBuckets; b += kScanThreads) { const uint32_t n = bcount[b]; bcount[b] = n ? atomicAdd(&p.bucket_count[b], n) : 0u; }
+    __syncthreads();
+    for (int c = tid; c < p.P; c += kScanThreads) {
+        const uint32_t lr = lrank[c];
+        if (lr != 0xffffffffu) {
+            const uint32_t b = lr >> 16;
+            p.bucket_list[(size_t)b * p.list_stride + bcount[b] + (lr & 0xffffu)] = f * (uint32_t)p.P + (uint32_t)c;
+        }
+    }
     // big frames only: running offsets per class over the tiles, in tile (= input) order
     if (big) for (int w = tid; w < p.P * parts; w += kScanThreads) {
         const int c = w % p.P, pt = w / p.P;
@@ -1093,7 +1105,8 @@ void launch_bin(const DevParams& p, hipStream_t s)
 void launch_scan(const DevParams& p, hipStream_t s)
 {
     if (p.frame_count == 0) return;
-    hipLaunchKernelGGL(scan_offsets_kernel, dim3(p.frame_count), dim3(kScanThreads), (size_t)p.PB * 17 * 4, s, p);
+    int parts = kScanThreads / (p.P + 4); if (parts > 16) parts = 16; if (parts < 1) parts = 1;      // as in the kernel
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(p.frame_count), dim3(kScanThreads), (size_t)p.PB * (2 + parts) * 4, s, p);
 }
 void launch_fit(const DevParams& p, hipStream_t s)
 {
