@@ -140,6 +140,9 @@ def main():
                     help="also time batches of ONE frame (extra launches of the same kernels; off by default so that "
                          "rocprofv3 --stats averages describe the bench batch only)")
     ap.add_argument("--no-profile-events", action="store_true")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="also time the PCIe-inclusive pipeline (pinned host xyz in, labels back to pinned host memory, "
+                         "copies and kernels of consecutive batches overlapped on the streams); reported beside `value`, never as it")
     args = ap.parse_args()
 
     import torch
@@ -255,6 +258,34 @@ def main():
             torch.cuda.synchronize()
         lat_ms = 1e3 * (time.perf_counter() - t1) / reps
 
+    # PCIe-inclusive pipeline, informational (SURVEY.md 8d "end-to-end"): every batch is copied in from pinned host
+    # memory and its labels are copied back, on the batch's own stream, so copies overlap other batches' kernels
+    e2e = None
+    if world == 1 and args.end_to_end:
+        h_xyz = torch.from_numpy(xyz_host).pin_memory()
+        h_lab = [torch.empty(total_pts, dtype=torch.uint8).pin_memory() for _ in range(n_streams)]
+        d_in = [torch.empty_like(d_xyz) for _ in range(n_streams)]
+
+        def e2e_step(i):
+            k = i % n_streams
+            with torch.cuda.stream(streams[k]):
+                d_in[k].copy_(h_xyz, non_blocking=True)
+                engines[k].segment_batch_device(d_in[k].data_ptr(), offsets, d_labels_all[k].data_ptr(), None,
+                                                streams[k].cuda_stream)
+                h_lab[k].copy_(d_labels_all[k], non_blocking=True)
+        for i in range(n_streams):
+            e2e_step(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            e2e_step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        same = bool(torch.equal(h_lab[0], d_labels_all[0].cpu()))
+        e2e = {"frames_per_sec": round(F * args.steps / dt, 2), "ms_per_step": round(1e3 * dt / args.steps, 4),
+               "host_GBps": round((12 + 1) * total_pts * args.steps / dt / 1e9, 2), "labels_match_device_run": same,
+               "includes": "H2D of the xyz batch + D2H of the labels over PCIe from/to pinned host memory, per batch, on its stream"}
+
     if rank == 0:
         frames_total = F * world * args.steps
         fps = frames_total / elapsed
@@ -274,6 +305,8 @@ def main():
             "ms_per_frame": round(1e3 * elapsed / (F * args.steps), 5),
             "single_frame_latency_ms": None if lat_ms is None else round(lat_ms, 4),
         }
+        if e2e is not None:
+            out["end_to_end"] = e2e
         if kms is not None:
             fit_ms, fit_n = kms["patch_fit"]
             dom = max(kms, key=lambda k: kms[k][0])
