@@ -372,7 +372,13 @@ constexpr int kSlotFloats = 6 * kLdw;
 struct Raw { float x, y, z; uint32_t m; };
 
 struct FitShared {
-    __attribute__((aligned(16))) float ring[kRing * kSlotFloats];
+    union {                            // the gather prologue is over before the first chained sweep
+        __attribute__((aligned(16))) float ring[kRing * kSlotFloats];
+        struct {
+            uint32_t toff[kGatherTiles];   // gather prologue: this patch's destination offset per tile of the frame
+            uint32_t tsrc[kGatherTiles];   // gather prologue: this patch's source slot per tile of the frame
+        } dir;
+    };
     float bc[16];                      // broadcast: chain sums, plane
     unsigned long long chain_addends;  // addends handed to the chains so far (per accumulator row); producer lane 0 only
     uint32_t nslots;                   // chain_pass: number of compacted ring slots (kOpen while the producer is still working)
@@ -380,9 +386,8 @@ struct FitShared {
     float fred[2][8];                  // per-wave partial min / max
     uint32_t hist[256];
     uint32_t stk[3 * kStackDepth];
-    uint32_t toff[kGatherTiles];       // gather prologue: this patch's destination offset per tile of the frame
-    uint32_t tsrc[kGatherTiles];       // gather prologue: this patch's source slot per tile of the frame
 };
+static_assert(sizeof(float) * kRing * kSlotFloats >= 2 * sizeof(uint32_t) * kGatherTiles, "the run directory must fit in the ring's space");
 
 struct FitCtx {
     // raw pointers by value: taking the address of the kernel-argument struct would push it to scratch
@@ -745,8 +750,8 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
         const uint32_t t0 = p.tile_base[frame];
         const uint32_t nt = p.tile_base[frame + 1] - t0;
         const bool in_lds = nt <= (uint32_t)kGatherTiles;
-        uint32_t* toff = sh.toff;                                       // destination offset of the run, per tile
-        uint32_t* tsrc = sh.tsrc;                                       // frame-relative source slot of the run, per tile
+        uint32_t* toff = sh.dir.toff;                                       // destination offset of the run, per tile
+        uint32_t* tsrc = sh.dir.tsrc;                                       // frame-relative source slot of the run, per tile
         const uint32_t* goff = p.hist + (size_t)t0 * p.PB + patch;      // stride PB: run lengths (offsets for a big frame)
         const uint32_t* gdir = p.tdir + (size_t)t0 * p.PB + patch;      // stride PB
         if (in_lds) {
