@@ -98,7 +98,7 @@ def load_pmc_traffic(kernel: str, frames_per_launch: int):
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_bench.json")
     try:
         d = json.load(open(path))
-        if frames_per_launch != 256:
+        if d.get("_meta", {}).get("frames_per_launch", 256) != frames_per_launch:
             return None, None
         v = d.get(kernel + "_kernel")
         return (int(v["hbm_bytes_per_launch"]), "profiles/r01_pmc_traffic_bench.json") if v else (None, None)
@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=18)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (one batch)")
+    ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (one batch)")
     ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (HIP streams, one engine each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-frame-latency", action="store_true",

@@ -317,3 +317,44 @@ def test_huge_frame_and_huge_patches(engine_factory):
     labels, res, st = eng.segment(xyz, want_residual=True)
     ref = assert_frame_parity(xyz, labels, res, st, eng.nodes(1 << 16), oc, tag="huge")
     assert ref.nodes["len"].max() > 300000
+
+
+def test_maximum_sector_count(engine_factory):
+    """num_sectors = 128 (the limit): 1024 patches per frame, histogram rows of 1028 classes; a batch of two frames."""
+    import torch
+    frames = [W.c2_hdl64(11), W.c1_test_cloud(12)]
+    pc, oc = cfg_pair(num_sectors=128, max_split_depth=2)
+    off = np.zeros(len(frames) + 1, np.uint32); off[1:] = np.cumsum([len(f) for f in frames])
+    eng = engine_factory(pc, max_points=int(off[-1]), max_frames=len(frames))
+    d = torch.from_numpy(np.concatenate(frames)).cuda()
+    lab = torch.empty(int(off[-1]), dtype=torch.uint8, device="cuda")
+    res = torch.empty(int(off[-1]), dtype=torch.float32, device="cuda")
+    eng.segment_batch_device(d.data_ptr(), off, lab.data_ptr(), res.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = eng.batch_stats(len(frames))
+    L, R = lab.cpu().numpy(), res.cpu().numpy()
+    for f, xyz in enumerate(frames):
+        sl = slice(int(off[f]), int(off[f + 1]))
+        assert_frame_parity(xyz, L[sl], R[sl], {k: st[k][f] for k in st.dtype.names}, None, oc, check_nodes=False, tag=f"S128-frame{f}")
+
+
+def test_batch_mixing_a_huge_frame_with_small_ones(engine_factory):
+    """Frames of more than kGatherTiles tiles take the global run directory (offsets made by scan_offsets), the others
+    scan their run lengths in LDS: both kinds in ONE batch, the huge frame in the middle."""
+    import torch
+    a = W.c5_dense(1)
+    huge = np.concatenate([a, a[::-1] * np.float32(0.999), a[:150000] * np.float32(0.7)])
+    assert len(huge) > 1024 * 2048
+    frames = [W.c1_test_cloud(21), huge, W.c2_hdl64(22)]
+    pc, oc = cfg_pair(max_iter=6, max_split_depth=2)
+    off = np.zeros(len(frames) + 1, np.uint32); off[1:] = np.cumsum([len(f) for f in frames])
+    eng = engine_factory(pc, max_points=int(off[-1]), max_frames=len(frames))
+    d = torch.from_numpy(np.concatenate(frames)).cuda()
+    lab = torch.empty(int(off[-1]), dtype=torch.uint8, device="cuda")
+    eng.segment_batch_device(d.data_ptr(), off, lab.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = eng.batch_stats(len(frames))
+    L = lab.cpu().numpy()
+    for f, xyz in enumerate(frames):
+        sl = slice(int(off[f]), int(off[f + 1]))
+        assert_frame_parity(xyz, L[sl], None, {k: st[k][f] for k in st.dtype.names}, None, oc, check_nodes=False, tag=f"mixed-frame{f}")

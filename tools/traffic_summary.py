@@ -12,7 +12,7 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(files[0])):
         if r["Counter_Name"] != cname:
             continue
-        kn = r["Kernel_Name"].split("(")[0].replace("rpw::", "")
+        kn = r["Kernel_Name"].split("(")[0].replace("rpw::", "").replace("void ", "").split("<")[0]
         tot[kn] += float(r["Counter_Value"]); disp[kn].add(r["Dispatch_Id"])
     for kn, v in tot.items():
         res[kn][cname + "_per_launch"] = v / max(1, len(disp[kn]))
@@ -25,4 +25,10 @@ for kn, d in res.items():
     w = d.get("WRITE_SIZE_per_launch", 0.0) * 1024.0
     out[kn] = {"read_bytes_raw": f, "read_bytes_x2_gfx950": 2 * f, "write_bytes": w,
                "hbm_bytes_per_launch": 2 * f + w, "launches": d.get("launches_FETCH_SIZE")}
+try:     # the batch the counters belong to (bench.py only quotes them for the same batch size)
+    b = json.loads(open(os.path.join(root, "FETCH_SIZE.bench.json")).read().strip().splitlines()[-1])
+    out["_meta"] = {"frames_per_launch": b["config"]["frames_per_gpu_per_step"], "points_per_frame": b["config"]["points_per_frame"],
+                    "command": "tools/collect_traffic.sh (bench.py --steps 4 --warmup 1 --no-cpu-baseline)"}
+except Exception:
+    pass
 print(json.dumps(out, indent=1))
