@@ -169,14 +169,16 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
             if (p.residual) p.residual[fo + i] = -1.0f;
         }
         // stable rank inside the wave's sub-tile: one step per distinct class of the row
-        unsigned long long rem = ballot64(valid);
+        const unsigned long long vmask = ballot64(valid);
+        unsigned long long rem = vmask;
         while (rem) {
             const int first = __ffsll((long long)rem) - 1;
             const int c0 = __builtin_amdgcn_readlane(cls[r], first);      // `first` is wave-uniform: no LDS round trip
-            const unsigned long long m = ballot64(valid && cls[r] == c0);
+            const bool same = cls[r] == c0;                                // (an out-of-range lane may match: its offset is never used)
+            const unsigned long long m = ballot64(same) & vmask;
             const uint32_t old = mycnt[c0];
-            if (valid && cls[r] == c0) loff[r] = old + (uint32_t)mbcnt64(m);
-            if (lane == first) mycnt[c0] = old + (uint32_t)__popcll(m);
+            loff[r] = same ? old + (uint32_t)mbcnt64(m) : loff[r];
+            mycnt[c0] = old + (uint32_t)__popcll(m);                       // every lane stores the same value: no exec juggling
             rem &= ~m;
         }
     }

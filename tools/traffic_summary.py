@@ -30,5 +30,10 @@ try:     # the batch the counters belong to (bench.py only quotes them for the s
     out["_meta"] = {"frames_per_launch": b["config"]["frames_per_gpu_per_step"], "points_per_frame": b["config"]["points_per_frame"],
                     "command": "tools/collect_traffic.sh (bench.py --steps 4 --warmup 1 --no-cpu-baseline)"}
 except Exception:
-    pass
+    try:
+        b = json.loads(open(os.path.join(root, "FETCH_SIZE.probe.json")).read().strip().splitlines()[-1])
+        out["_meta"] = {"frames_per_launch": b["frames"], "points_per_launch": b["points"],
+                        "command": "PROBE=1 tools/collect_traffic.sh (tools/binning_probe.py, MAX_ITER=1)"}
+    except Exception:
+        pass
 print(json.dumps(out, indent=1))
