@@ -398,6 +398,8 @@ rpw_status rpw_create(const rpw_config* cfg, int device, uint32_t max_points, ui
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(nullptr, RPW_ERR_NO_DEVICE, "device %d is %s; kernels are built for gfx950 only", device, prop.gcnArchName);
     }
+    if (max_points > (1u << 30))      // patch_fit addresses its per-slot arrays with 32-bit byte offsets
+        return fail(nullptr, RPW_ERR_CAPACITY, "max_points %u > 1073741824", max_points);
     rpw_handle* h = new (std::nothrow) rpw_handle();
     if (!h) return fail(nullptr, RPW_ERR_INVALID, "out of host memory");
     std::memset(&h->sensors, 0, sizeof h->sensors);

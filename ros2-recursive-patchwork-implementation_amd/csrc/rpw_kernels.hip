@@ -430,15 +430,19 @@ __device__ __forceinline__ void flag_store(uint32_t* p, uint32_t v) { __hip_atom
 // An explicit s_waitcnt vmcnt(0) after a plain LDS store does not reproduce the gain (51 k), so it is kept as measured.
 __device__ __forceinline__ void publish_slots(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
 
+// uniform base + 32-bit byte offset: the loads take the SGPR-base form, no 64-bit address arithmetic per lane
+// (rpw_create keeps the capacity under 2^30 slots)
+__device__ __forceinline__ float ldg_f32(const float* base, uint32_t slot) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + slot * 4u); }
+
+// Slot min(i, n-1) of chunk `chunk`: lanes (and whole prefetched chunks) past the end read the node's last slot again
+// instead of being masked off -- no exec juggling, no zero fill; chain_pass never lets them take part (n >= 1).
 __device__ __forceinline__ Raw load_raw(const FitCtx& cx, uint32_t s, uint32_t n, uint32_t chunk)
 {
-    Raw r; r.x = 0.0f; r.y = 0.0f; r.z = 0.0f; r.m = 0u;
+    Raw r;
     const uint32_t i = chunk * kWave + cx.lane;
-    if (i < n) {
-        const uint32_t g = cx.base + s + i;
-        r.x = cx.sx[g]; r.y = cx.sy[g]; r.z = cx.sz[g];
-        r.m = (uint32_t)cx.mask[g];                   // raw byte: nothing here may depend on a load's result
-    }
+    const uint32_t g = cx.base + s + (i < n ? i : n - 1u);
+    r.x = ldg_f32(cx.sx, g); r.y = ldg_f32(cx.sy, g); r.z = ldg_f32(cx.sz, g);
+    r.m = (uint32_t)cx.mask[g];                       // raw byte: nothing here may depend on a load's result
     return r;
 }
 
@@ -446,6 +450,7 @@ __device__ __forceinline__ Raw load_raw(const FitCtx& cx, uint32_t s, uint32_t n
 
 // One chained pass over the node [s, s+n): K sequential sums, accumulator k in consumer lane k.
 // make(raw, i, ok, out[K]) -> bool: turns slot i (node-relative) into its K addends, may update the
+// (ok says whether slot i exists: side effects must respect it, the returned predicate need not)
 // slot's mask byte, and says whether the slot takes part at all. Slots that do not are SKIPPED: the
 // producer compacts the addends (ballot + mbcnt keep slot order), so the chain is as long as the number
 // of participating slots, not as the node. post() runs once on the producer wave after its last chunk
@@ -472,9 +477,12 @@ __device__ __forceinline__ void chain_pass(const FitCtx& cx, uint32_t s, uint32_
         auto fill2 = [&](uint32_t chunk, const Raw& ra, const Raw& rb) __attribute__((always_inline)) {
             float va[K], vb[K];
             const uint32_t ia = chunk * kWave + cx.lane, ib = ia + kWave;
-            const bool ina = make(ra, ia, ia < n, va);
-            const bool inb = make(rb, ib, ib < n, vb);
-            const unsigned long long ma = ballot64(ina), mb = ballot64(inb);
+            // make() returns the slot's own predicate; whether the slot exists is ANDed in as a mask (scalar)
+            const bool oka = ia < n, okb = ib < n;
+            const bool pra = make(ra, ia, oka, va);
+            const bool prb = make(rb, ib, okb, vb);
+            const unsigned long long ma = ballot64(pra) & ballot64(oka), mb = ballot64(prb) & ballot64(okb);
+            const bool ina = pra && oka, inb = prb && okb;
             const uint32_t ca = (uint32_t)__popcll(ma), cb = (uint32_t)__popcll(mb);
             const uint32_t pa = cursor + (uint32_t)mbcnt64(ma);
             const uint32_t pb = cursor + ca + (uint32_t)mbcnt64(mb);
@@ -582,7 +590,7 @@ struct PlaneD { float cx, cy, cz, nx, ny, nz, residual; };
 __device__ __forceinline__ void centroid_sums(const FitCtx& cx, uint32_t s, uint32_t n, int bit, float* cs)
 {
     chain_pass<3>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
-        const bool in = ok && ((r.m >> bit) & 1u);
+        const bool in = (r.m >> bit) & 1u;
         v[0] = r.x; v[1] = r.y; v[2] = r.z;
         return in;
     }, NoPost(), cs);
@@ -595,7 +603,7 @@ __device__ __forceinline__ void plane_from_sums(const FitCtx& cx, uint32_t s, ui
     const float c0 = cs[0] / fm, c1 = cs[1] / fm, c2 = cs[2] / fm;
     float cv[6];
     chain_pass<6>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
-        const bool in = ok && ((r.m >> bit) & 1u);
+        const bool in = (r.m >> bit) & 1u;
         const float dx = r.x - c0, dy = r.y - c1, dz = r.z - c2;
         v[0] = dx * dx;   // (0,0)
         v[1] = dy * dx;   // (1,0)
@@ -614,7 +622,7 @@ __device__ __forceinline__ float residual_masked(const FitCtx& cx, uint32_t s, u
 {
     float r1[1];
     chain_pass<1>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
-        const bool in = ok && ((r.m >> bit) & 1u);
+        const bool in = (r.m >> bit) & 1u;
         v[0] = plane_dist(r.x, r.y, r.z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
         return in;
     }, NoPost(), r1);
@@ -815,7 +823,7 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
         float sum[1];
         chain_pass<1>(cx, 0, pd.n, [&](const Raw& r, uint32_t, bool ok, float* v) {
             v[0] = sqrt_rn(r.x * r.x + r.y * r.y);
-            return ok;
+            return true;
         }, NoPost(), sum);
         mean_dist = sum[0] / (float)pd.n;
     }
@@ -888,9 +896,9 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
         {
             uint32_t seeds = 0;
             chain_pass<3>(cx, s, n, [&](const Raw& r, uint32_t i, bool ok, float* v) {
-                const bool seed = ok && r.z < z_th;
+                const bool seed = r.z < z_th;
                 if (ok) gm[i] = seed ? 1 : 0;
-                seeds += (uint32_t)__popcll(ballot64(seed));
+                seeds += (uint32_t)__popcll(ballot64(seed) & ballot64(ok));
                 v[0] = r.x; v[1] = r.y; v[2] = r.z;
                 return seed;
             }, [&]() { if (lane == 0) sh.red[1][0] = seeds; }, cs);
@@ -924,12 +932,12 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
             float fs[4];
             chain_pass<4>(cx, s, n, [&](const Raw& r, uint32_t i, bool ok, float* v) {
                 const float d = plane_dist(r.x, r.y, r.z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
-                const bool nw = ok && d < threshold;
-                const bool old = ok && (r.m & 1u), prev = ok && ((r.m >> 1) & 1u);
-                changed |= (nw != old);
-                differs_prev |= (nw != prev);
+                const bool nw = d < threshold;
+                const bool old = r.m & 1u, prev = (r.m >> 1) & 1u;
+                changed |= ok && (nw != old);
+                differs_prev |= ok && (nw != prev);
                 if (ok) gm[i] = (uint8_t)((nw ? 1u : 0u) | ((r.m & 0x7fu) << 1));
-                newcount += (uint32_t)__popcll(ballot64(nw));
+                newcount += (uint32_t)__popcll(ballot64(nw) & ballot64(ok));
                 // Compacted by the NEW mask. Row 3 carries |d| of the slots that are also in the OLD mask: it
                 // is the old-mask residual exactly when the two masks coincide, which is the only case it is used.
                 v[0] = r.x; v[1] = r.y; v[2] = r.z;
@@ -979,14 +987,14 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
             float m2[2], v2[2];
             chain_pass<2>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
                 v[0] = r.x; v[1] = r.y;
-                return ok;
+                return true;
             }, NoPost(), m2);
             const float fn = (float)n;
             const float mx = m2[0] / fn, my = m2[1] / fn;
             chain_pass<2>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
                 const float dx = r.x - mx, dy = r.y - my;
                 v[0] = dx * dx; v[1] = dy * dy;
-                return ok;
+                return true;
             }, NoPost(), v2);
             const float var_x = v2[0] / fn, var_y = v2[1] / fn;
             const int axis = (var_x > var_y) ? 0 : 1;
