@@ -604,13 +604,19 @@ __device__ __forceinline__ void plane_from_sums(const FitCtx& cx, uint32_t s, ui
     float cv[6];
     chain_pass<6>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
         const bool in = (r.m >> bit) & 1u;
-        const float dx = r.x - c0, dy = r.y - c1, dz = r.z - c2;
-        v[0] = dx * dx;   // (0,0)
-        v[1] = dy * dx;   // (1,0)
-        v[2] = dy * dy;   // (1,1)
-        v[3] = dz * dx;   // (2,0)
-        v[4] = dz * dy;   // (2,1)
-        v[5] = dz * dz;   // (2,2)
+        // two-wide float arithmetic (v_pk_add_f32 / v_pk_mul_f32: each half is an ordinary IEEE binary32 operation)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 dxy = f2{r.x, r.y} - f2{c0, c1};
+        const float dz = r.z - c2;
+        const f2 a = dxy * f2{dxy.x, dxy.x};            // dx*dx, dy*dx
+        const f2 b = f2{dxy.y, dz} * f2{dxy.y, dxy.x};  // dy*dy, dz*dx
+        const f2 c = f2{dz, dz} * f2{dxy.y, dz};        // dz*dy, dz*dz
+        v[0] = a.x;   // (0,0)
+        v[1] = a.y;   // (1,0)
+        v[2] = b.x;   // (1,1)
+        v[3] = b.y;   // (2,0)
+        v[4] = c.x;   // (2,1)
+        v[5] = c.y;   // (2,2)
         return in;
     }, NoPost(), cv);
     const float fm1 = (float)(m - 1);
