@@ -125,7 +125,9 @@ void        rpw_default_config(rpw_config* cfg);
 uint32_t    rpw_abi_version(void);
 
 /* device: HIP device ordinal. max_points: capacity in points of one batch (sum over its
- * frames). max_frames: capacity in frames of one batch. */
+ * frames), at most 2^30 (RPW_ERR_CAPACITY beyond: the kernels address a batch with 32-bit byte
+ * offsets); a single frame may hold at most 2^28 - 1 points. max_frames: capacity in frames of
+ * one batch. Device memory taken: about 70 bytes per point of capacity. */
 rpw_status  rpw_create(const rpw_config* cfg, int device, uint32_t max_points, uint32_t max_frames,
                        rpw_handle** out);
 void        rpw_destroy(rpw_handle* h);

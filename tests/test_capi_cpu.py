@@ -106,3 +106,13 @@ def test_atan2f_model_is_libm_bit_for_bit():
         if a < 0:
             a = np.float32(np.float64(a) + 6.283185307179586)
         assert a.view(np.uint32) == got[i].view(np.uint32) or (a == 0 and got[i] == 0), (i, X[i], Y[i], a, got[i])
+
+
+def test_capacity_limit_is_checked_before_the_device_is_touched():
+    """max_points above 2^30 is refused (32-bit byte offsets inside the kernels); on this CPU box the device check comes first."""
+    lib = rpw_amd.load_library()
+    h = C.c_void_p()
+    c = rpw_amd.PatchworkConfig().to_c()
+    st = lib.rpw_create(C.byref(c), 0, (1 << 30) + 1, 1, C.byref(h))
+    assert st != 0 and not h.value
+    assert lib.rpw_last_error(None)
