@@ -386,6 +386,7 @@ struct FitShared {
     uint32_t nslots;                   // chain_pass: number of compacted ring slots (kOpen while the producer is still working)
     uint32_t red[2][8];                // per-wave partial counts / flags
     float fred[2][8];                  // per-wave partial min / max
+    float rootbox[2][8];               // per-wave bounding box of the whole patch, taken by the gather
     uint32_t hist[256];
     uint32_t stk[3 * kStackDepth];
 };
@@ -789,31 +790,59 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
         }
         __syncthreads();
         const uint32_t rel0 = in_lds ? 0u : pd.begin - fo;              // LDS offsets are patch-relative, global ones frame-relative
-        auto source_of = [&](uint32_t j) -> uint32_t {                  // tile-sorted slot that feeds patch slot j
-            const uint32_t d = rel0 + j;
-            uint32_t lo = 0, hi = nt;
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                const uint32_t v = in_lds ? toff[mid] : goff[(size_t)mid * p.PB];
-                if (v <= d) lo = mid; else hi = mid;
+        // Tile-sorted slot that feeds patch slot j: the LAST tile whose offset is <= d = rel0 + j. A fixed number of
+        // halving steps (the same for every lane and element), written with the STEP loop outside and the elements a
+        // thread handles in one round inside: their searches advance together, one LDS round trip per step for all of
+        // them (eight separate search loops cost 48 dependent round trips per round and made the gather 22 % of the
+        // largest patch's lifetime).
+        uint32_t top = 1; while (top * 2u < nt) top *= 2u;               // largest power of two < nt (nt >= 1), uniform
+        // kGatherWide independent elements per thread and round: their searches overlap in the LDS queue and their
+        // 16-byte loads are in flight together (the pass is latency-bound: HBM round trips, not bytes). The bounding
+        // box of the whole patch (the root node's early-out test) is taken here, while the points are in registers.
+        constexpr int kGatherWide = 8;
+        float xmn = 3.402823466e+38f, xmx = -3.402823466e+38f, ymn = xmn, ymx = xmx, zmn = xmn, zmx = xmx;
+        for (uint32_t j0 = tid; j0 < pd.n; j0 += kGatherWide * kFitThreads) {
+            uint32_t src[kGatherWide], d[kGatherWide], lo[kGatherWide]; float4 v4[kGatherWide];
+#pragma unroll
+            for (int u = 0; u < kGatherWide; ++u) { const uint32_t j = j0 + u * kFitThreads; d[u] = rel0 + (j < pd.n ? j : pd.n - 1u); lo[u] = 0; }
+            if (in_lds) {
+                for (uint32_t step = top; step > 0; step >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < kGatherWide; ++u) {
+                        const uint32_t mid = lo[u] + step, mc = mid < nt ? mid : nt - 1u;
+                        lo[u] = (mid < nt && toff[mc] <= d[u]) ? mid : lo[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kGatherWide; ++u) src[u] = fo + tsrc[lo[u]] + (d[u] - toff[lo[u]]);
+            } else {
+                for (uint32_t step = top; step > 0; step >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < kGatherWide; ++u) {
+                        const uint32_t mid = lo[u] + step, mc = mid < nt ? mid : nt - 1u;
+                        lo[u] = (mid < nt && goff[(size_t)mc * p.PB] <= d[u]) ? mid : lo[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kGatherWide; ++u)
+                    src[u] = fo + lo[u] * kTilePoints + gdir[(size_t)lo[u] * p.PB] + (d[u] - goff[(size_t)lo[u] * p.PB]);
             }
-            const uint32_t o = in_lds ? toff[lo] : goff[(size_t)lo * p.PB];
-            const uint32_t sb = in_lds ? tsrc[lo] : lo * kTilePoints + gdir[(size_t)lo * p.PB];
-            return fo + sb + (d - o);
-        };
-        // four independent elements per thread and round: their loads are in flight together
-        for (uint32_t j0 = tid; j0 < pd.n; j0 += 4 * kFitThreads) {
-            uint32_t src[4]; float4 v4[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t j = j0 + u * kFitThreads; src[u] = j < pd.n ? source_of(j) : 0u; }
+            for (int u = 0; u < kGatherWide; ++u) v4[u] = p.tp[src[u]];            // past the end: the last slot again
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (j0 + u * kFitThreads < pd.n) v4[u] = p.tp[src[u]];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kGatherWide; ++u) {
                 const uint32_t j = j0 + u * kFitThreads;
-                if (j < pd.n) { const uint32_t dst = pd.begin + j; p.sx[dst] = v4[u].x; p.sy[dst] = v4[u].y; p.sz[dst] = v4[u].z; p.sidx[dst] = __float_as_uint(v4[u].w); }
+                if (j < pd.n) {
+                    const uint32_t dst = pd.begin + j;
+                    p.sx[dst] = v4[u].x; p.sy[dst] = v4[u].y; p.sz[dst] = v4[u].z; p.sidx[dst] = __float_as_uint(v4[u].w);
+                }
+                // min/max are idempotent: a repeated last slot changes nothing
+                xmn = fminf(xmn, v4[u].x); xmx = fmaxf(xmx, v4[u].x); ymn = fminf(ymn, v4[u].y); ymx = fmaxf(ymx, v4[u].y);
+                zmn = fminf(zmn, v4[u].z); zmx = fmaxf(zmx, v4[u].z);
             }
         }
+        xmn = wave_min(xmn); xmx = wave_max(xmx); ymn = wave_min(ymn); ymx = wave_max(ymx); zmn = wave_min(zmn); zmx = wave_max(zmx);
+        if (lane == 0) { float* f = sh.rootbox[wave]; f[0] = xmn; f[1] = xmx; f[2] = ymn; f[3] = ymx; f[4] = zmn; f[5] = zmx; }
         __syncthreads();
     }
 
@@ -862,18 +891,28 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
         if (n < 3 || depth > cfg.max_split_depth) leaf_kind = RPW_NODE_REJECT;
         if (leaf_kind < 0) {
             float xmn = 3.402823466e+38f, xmx = -3.402823466e+38f, ymn = xmn, ymx = xmx, zmn = xmn, zmx = xmx;
-            for (uint32_t i = tid; i < n; i += kFitThreads) {
-                const float x = gx[i], y = gy[i], z = gz[i];
-                xmn = fminf(xmn, x); xmx = fmaxf(xmx, x); ymn = fminf(ymn, y); ymx = fmaxf(ymx, y);
-                zmn = fminf(zmn, z); zmx = fmaxf(zmx, z);
+            const float (*box)[8] = sh.rootbox;                // the root node: the gather has taken its box already
+            if (depth > 0) {
+                box = sh.fred;
+                // four elements per thread and round in flight (the pass is latency-bound)
+                for (uint32_t i0 = tid; i0 < n; i0 += 4 * kFitThreads) {
+                    float x[4], y[4], z[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * kFitThreads, ic = i < n ? i : n - 1u; x[u] = gx[ic]; y[u] = gy[ic]; z[u] = gz[ic]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        xmn = fminf(xmn, x[u]); xmx = fmaxf(xmx, x[u]); ymn = fminf(ymn, y[u]); ymx = fmaxf(ymx, y[u]);
+                        zmn = fminf(zmn, z[u]); zmx = fmaxf(zmx, z[u]);
+                    }
+                }
+                xmn = wave_min(xmn); xmx = wave_max(xmx); ymn = wave_min(ymn); ymx = wave_max(ymx);
+                zmn = wave_min(zmn); zmx = wave_max(zmx);
+                if (lane == 0) { float* f = sh.fred[wave]; f[0] = xmn; f[1] = xmx; f[2] = ymn; f[3] = ymx; f[4] = zmn; f[5] = zmx; }
+                __syncthreads();
             }
-            xmn = wave_min(xmn); xmx = wave_max(xmx); ymn = wave_min(ymn); ymx = wave_max(ymx);
-            zmn = wave_min(zmn); zmx = wave_max(zmx);
-            if (lane == 0) { float* f = sh.fred[wave]; f[0] = xmn; f[1] = xmx; f[2] = ymn; f[3] = ymx; f[4] = zmn; f[5] = zmx; }
-            __syncthreads();
-            xmn = fminf(sh.fred[0][0], sh.fred[1][0]); xmx = fmaxf(sh.fred[0][1], sh.fred[1][1]);
-            ymn = fminf(sh.fred[0][2], sh.fred[1][2]); ymx = fmaxf(sh.fred[0][3], sh.fred[1][3]);
-            zmn = fminf(sh.fred[0][4], sh.fred[1][4]); zmx = fmaxf(sh.fred[0][5], sh.fred[1][5]);
+            xmn = fminf(box[0][0], box[1][0]); xmx = fmaxf(box[0][1], box[1][1]);
+            ymn = fminf(box[0][2], box[1][2]); ymx = fmaxf(box[0][3], box[1][3]);
+            zmn = fminf(box[0][4], box[1][4]); zmx = fmaxf(box[0][5], box[1][5]);
             __syncthreads();
             const float area = (xmx - xmn) * (ymx - ymn);
             if (area < 25.0f && depth > 0) leaf_kind = RPW_NODE_SMALL;
@@ -1052,18 +1091,25 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
 
         // ---- FIT leaf: labels (and residuals) -----------------------------------------------------
         pa.iters += (unsigned long long)iters;
-        for (uint32_t i = tid; i < n; i += kFitThreads) {
-            const uint32_t orig = gi[i];
-            p.labels[fo + orig] = ((gm[i] >> final_bit) & 1u) ? RPW_LABEL_GROUND : RPW_LABEL_NONGROUND;
-            if (p.residual) {
-                float x, y, z;
-                if (permuted) {
-                    P3 q = load_point(p, fo + orig);
-                    if (p.sensors.n) (void)fuse_point(p, (uint32_t)frame, orig, q);     // the point as the fused cloud holds it
-                    x = q.x; y = q.y; z = q.z;
+        for (uint32_t i0 = tid; i0 < n; i0 += 4 * kFitThreads) {          // four slots per thread and round in flight
+            uint32_t orig[4], m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * kFitThreads, ic = i < n ? i : n - 1u; orig[u] = gi[ic]; m[u] = gm[ic]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * kFitThreads;
+                if (i >= n) continue;
+                p.labels[fo + orig[u]] = ((m[u] >> final_bit) & 1u) ? RPW_LABEL_GROUND : RPW_LABEL_NONGROUND;
+                if (p.residual) {
+                    float x, y, z;
+                    if (permuted) {
+                        P3 q = load_point(p, fo + orig[u]);
+                        if (p.sensors.n) (void)fuse_point(p, (uint32_t)frame, orig[u], q);     // the point as the fused cloud holds it
+                        x = q.x; y = q.y; z = q.z;
+                    }
+                    else { x = gx[i]; y = gy[i]; z = gz[i]; }
+                    p.residual[fo + orig[u]] = plane_dist(x, y, z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
                 }
-                else { x = gx[i]; y = gy[i]; z = gz[i]; }
-                p.residual[fo + orig] = plane_dist(x, y, z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
             }
         }
         pa.ground += count;
