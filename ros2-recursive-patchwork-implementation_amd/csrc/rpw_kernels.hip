@@ -807,14 +807,14 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
             for (int u = 0; u < kGatherWide; ++u) { const uint32_t j = j0 + u * kFitThreads; d[u] = rel0 + (j < pd.n ? j : pd.n - 1u); lo[u] = 0; }
             if (in_lds) {
                 for (uint32_t step = top; step > 0; step >>= 1) {
+                    uint32_t v[kGatherWide];
 #pragma unroll
-                    for (int u = 0; u < kGatherWide; ++u) {
-                        const uint32_t mid = lo[u] + step, mc = mid < nt ? mid : nt - 1u;
-                        lo[u] = (mid < nt && toff[mc] <= d[u]) ? mid : lo[u];
-                    }
+                    for (int u = 0; u < kGatherWide; ++u) { const uint32_t mid = lo[u] + step; v[u] = toff[mid < nt ? mid : nt - 1u]; }   // all reads first
+#pragma unroll
+                    for (int u = 0; u < kGatherWide; ++u) { const uint32_t mid = lo[u] + step; lo[u] = ((mid < nt) & (v[u] <= d[u])) ? mid : lo[u]; }
                 }
 #pragma unroll
-                for (int u = 0; u < kGatherWide; ++u) src[u] = fo + tsrc[lo[u]] + (d[u] - toff[lo[u]]);
+                for (int u = 0; u < kGatherWide; ++u) { const uint32_t o = toff[lo[u]], sb = tsrc[lo[u]]; src[u] = fo + sb + (d[u] - o); }
             } else {
                 for (uint32_t step = top; step > 0; step >>= 1) {
 #pragma unroll
