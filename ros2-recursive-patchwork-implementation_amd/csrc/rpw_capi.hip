@@ -67,13 +67,6 @@ struct rpw_handle {
 
     // host-pointer path
     hipStream_t own_stream = nullptr;
-    hipStream_t aux_stream = nullptr;    // second lane of the binning pipeline (large batches)
-    std::vector<hipEvent_t> sync_events;
-    // Experimental (RPW_GROUP_MB): cut the binning pass of a large batch into groups of frames so that K3 re-reads
-    // xyz from the Infinity Cache. Measured on 32 dense frames it LOSES (0.49 -> 0.58..1.0 ms): every extra group
-    // costs three more launches (host-bound at ~5 us each) and, with two streams, two cross-stream event waits.
-    // Off by default; a hipGraph capture of the grouped pipeline is what would make it pay.
-    uint64_t group_bytes = 0;
     float* d_in = nullptr;
     unsigned char* d_raw = nullptr;      // raw PointCloud2 bytes (rpw_segment_pointcloud2)
     size_t raw_bytes = 0;
@@ -307,55 +300,11 @@ rpw_status run_batch(rpw_handle* h, const void* d_xyz, const uint32_t* frame_off
     p.mask = h->d_mask; p.stats = h->d_stats;
     p.trace = (h->trace && h->d_nodes) ? 1 : 0; p.nodes = h->d_nodes; p.node_count = h->d_ctrl + kBuckets; p.nodes_cap = h->nodes_cap;
 
-    // ---- binning pass --------------------------------------------------------------------------------------
-    // Small batches: K1, K2, K3 once over everything. Large batches are cut into groups of frames of about
-    // group_bytes of xyz and software-pipelined over two streams: K3 of group g re-reads the xyz that K1 of
-    // group g pulled through the Infinity Cache a moment ago (instead of from HBM), while K1 of group g+1
-    // (VALU-bound) runs beside it (HBM-bound).
-    std::vector<uint32_t> gstart;      // first frame of every group
-    {
-        uint64_t acc = 0; gstart.push_back(0);
-        for (uint32_t f = 0; f < F; ++f) {
-            const uint64_t b = (uint64_t)(frame_offsets[f + 1] - frame_offsets[f]) * 12ull;
-            if (h->group_bytes && acc && acc + b > h->group_bytes) { gstart.push_back(f); acc = 0; }
-            acc += b;
-        }
-        gstart.push_back(F);
-    }
-    const size_t n_groups = gstart.size() - 1;
-    auto group_params = [&](size_t g) {
-        DevParams q = p;
-        q.frame_first = gstart[g]; q.frame_count = gstart[g + 1] - gstart[g];
-        q.tile_first = ho[(F + 1) + gstart[g]]; q.tile_count = ho[(F + 1) + gstart[g + 1]] - q.tile_first;
-        return q;
-    };
-    if (n_groups <= 1) {
-        const DevParams q = group_params(0);
-        timed(h, RPW_K_BIN, stream, [&] { launch_bin(q, stream); });
-        timed(h, RPW_K_SCAN, stream, [&] { launch_scan(q, stream); });
-    } else {
-        const bool two_lanes = std::getenv("RPW_ONE_LANE") == nullptr;
-        if (two_lanes && !h->aux_stream) RPW_HIP(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-        hipStream_t aux = two_lanes ? h->aux_stream : stream;
-        while (h->sync_events.size() < n_groups + 1) {
-            hipEvent_t e = nullptr;
-            RPW_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            h->sync_events.push_back(e);
-        }
-        for (size_t g = 0; g < n_groups; ++g) {
-            const DevParams q = group_params(g);
-            timed(h, RPW_K_BIN, stream, [&] { launch_bin(q, stream); });
-            if (two_lanes) {
-                RPW_HIP(h, hipEventRecord(h->sync_events[g], stream));
-                RPW_HIP(h, hipStreamWaitEvent(aux, h->sync_events[g], 0));
-            }
-            timed(h, RPW_K_SCAN, aux, [&] { launch_scan(q, aux); });
-        }
-        if (two_lanes) {
-            RPW_HIP(h, hipEventRecord(h->sync_events[n_groups], aux));
-            RPW_HIP(h, hipStreamWaitEvent(stream, h->sync_events[n_groups], 0));
-        }
-    }
+    // ---- binning pass: K1 and K2 once over the whole batch, then K3 ---------------------------------------------
+    // (A variant that cut large batches into groups of frames and pipelined K1 / K2 over two streams, so that K3
+    // would find the xyz still in the Infinity Cache, was measured slower -- launch-bound -- and removed.)
+    timed(h, RPW_K_BIN, stream, [&] { launch_bin(p, stream); });
+    timed(h, RPW_K_SCAN, stream, [&] { launch_scan(p, stream); });
     timed(h, RPW_K_FIT, stream, [&] { launch_fit(p, stream); });
     RPW_HIP(h, hipGetLastError());
     return RPW_OK;
@@ -404,10 +353,9 @@ rpw_status rpw_create(const rpw_config* cfg, int device, uint32_t max_points, ui
     if (!h) return fail(nullptr, RPW_ERR_INVALID, "out of host memory");
     std::memset(&h->sensors, 0, sizeof h->sensors);
     h->cfg = c; h->device = device; h->max_points = max_points; h->max_frames = max_frames ? max_frames : 1;
-    // Streams are created lazily (own_stream by the host-pointer path, aux_stream by the grouped binning
-    // pipeline): ROCm multiplexes all streams of a process onto a few hardware queues, and an idle extra
-    // stream per handle is enough to make the caller's streams share queues and serialise.
-    if (const char* gb = std::getenv("RPW_GROUP_MB")) h->group_bytes = (uint64_t)std::strtoull(gb, nullptr, 10) << 20;
+    // The handle's own stream is created lazily (by the host-pointer path): ROCm multiplexes all streams of a
+    // process onto a few hardware queues, and an idle extra stream per handle is enough to make the caller's
+    // streams share queues and serialise.
     st = allocate(h);
     if (st != RPW_OK) { g_create_error = h->err; rpw_destroy(h); return st; }
     *out = h;
@@ -422,9 +370,7 @@ void rpw_destroy(rpw_handle* h)
     drain_profile(h);
     for (hipEvent_t e : h->free_events) (void)hipEventDestroy(e);
     free_device(h);
-    for (hipEvent_t ev : h->sync_events) (void)hipEventDestroy(ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
-    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     delete h;
 }
 

@@ -28,7 +28,7 @@ e1.record(); torch.cuda.synchronize()
 call_ms = e0.elapsed_time(e1) / reps
 k = {n: v[0] / max(1, v[1]) for n, v in eng.kernel_ms().items()}
 binms = k["bin_tile"] + k["scan_offsets"]
-print(json.dumps({"group_mb": os.environ.get("RPW_GROUP_MB", "64"), "call_ms": round(call_ms, 4), "call_minus_fit_ms": round(call_ms - k["patch_fit"], 4),
+print(json.dumps({"call_ms": round(call_ms, 4), "call_minus_fit_ms": round(call_ms - k["patch_fit"], 4),
                   "binning_wall_GBps_alg28": round(28 * N / max(1e-9, call_ms - k["patch_fit"]) / 1e6, 1), "frames": B, "points": N, "input_MB": round(N * 12 / 1e6, 1), "ms": {n: round(v, 4) for n, v in k.items()},
                   "binning_ms": round(binms, 4), "binning_GBps_alg28": round(28 * N / binms / 1e6, 1),
                   "frac_of_8TBps": round(28 * N / binms / 1e6 / 8000, 4),
