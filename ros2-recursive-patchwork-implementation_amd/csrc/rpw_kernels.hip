@@ -239,7 +239,7 @@ __device__ __forceinline__ int size_bucket(uint32_t n)
 
 constexpr int kScanThreads = 256;     // small blocks: a 1024-thread block cannot be placed while patch_fit waves of other streams fill the CUs
 
-__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* red /*[16]*/, uint32_t& total)
+__device__ __forceinline__ uint32_t scan_block_excl_scan(uint32_t v, uint32_t* red /*[kScanThreads / 64]*/, uint32_t& total)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t incl = wave_incl_scan(v);
@@ -307,8 +307,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
         const int c = c0 + tid;
         const uint32_t v = c < p.P ? tot[c] : 0u;
         uint32_t total, nz_total;
-        const uint32_t ex = block_excl_scan_1024(v, red, total);
-        (void)block_excl_scan_1024(v > 0 ? 1u : 0u, red, nz_total);
+        const uint32_t ex = scan_block_excl_scan(v, red, total);
+        (void)scan_block_excl_scan(v > 0 ? 1u : 0u, red, nz_total);
         if (c < p.P) {
             const uint32_t begin = running + ex;
             tot[c] = begin;
