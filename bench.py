@@ -35,11 +35,22 @@ BYTES_PER_POINT_FIT = 17        # 12 sorted xyz + 4 index + 1 la
 BYTES_PER_POINT_BIN = 28        # 12 xyz in + 12 sorted SoA out + 4 index out
 
 
-def make_frames(n_frames: int, rank: int):
-    """C2/C3 workload: 8 seeded HDL-64-like base frames, further frames are yaw-rotated copies."""
+WORKLOADS = {   # name: (generator, config, default frames per step, description) -- BASELINE.json `configs`
+    "c2": ("c2_hdl64", dict(max_split_depth=3), 512,
+           "c2_hdl64 (BASELINE.json configs[1]/[2]): seeded HDL-64-like ray-cast frames"),
+    "c1": ("c1_test_cloud", dict(), 2048, "c1_test_cloud (configs[0]): the reference test's 20 k-point clouds"),
+    "c4": ("c4_iac_fused", dict(max_split_depth=1000), 256,
+           "c4_iac_fused (configs[3]): 3 fused solid-state sensors, ~296 k points, deep recursion allowed"),
+    "c5": ("c5_dense", dict(max_split_depth=6), 64, "c5_dense (configs[4]): dense 1.09 M-point frames"),
+}
+
+
+def make_frames(n_frames: int, rank: int, workload: str = "c2"):
+    """8 seeded base frames of the workload (C2/C3 by default), further frames are yaw-rotated copies."""
     import rpw_amd
     W = rpw_amd.workloads
-    base = [W.c2_hdl64(seed) for seed in range(min(8, n_frames))]
+    gen = getattr(W, WORKLOADS[workload][0])
+    base = [gen(seed) for seed in range(min(8 if workload != "c5" else 4, n_frames))]
     frames = []
     for i in range(n_frames):
         b = base[i % len(base)]
@@ -133,7 +144,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=18)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (one batch)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
+                    help="c2 (default) is the configuration the metric is quoted on; the others are informational")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (one batch); 0 = the workload's default (c2: 512)")
     ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (HIP streams, one engine each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-frame-latency", action="store_true",
@@ -162,8 +175,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    cfg_kw = dict(max_split_depth=3)                                   # configs[1]: recursion depth = 3
-    frames = make_frames(args.frames, rank)
+    wl_gen, cfg_kw, wl_frames, wl_desc = WORKLOADS[args.workload]      # c2 = configs[1]: recursion depth = 3
+    if args.frames <= 0:
+        args.frames = wl_frames
+    frames = make_frames(args.frames, rank, args.workload)
     offsets = np.zeros(len(frames) + 1, np.uint32)
     offsets[1:] = np.cumsum([len(f) for f in frames])
     total_pts = int(offsets[-1])
@@ -301,11 +316,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "c2_hdl64 (BASELINE.json configs[1]/[2]): seeded HDL-64-like ray-cast frames, "
-                            "inputs resident in HBM, labels left in HBM",
+                "workload": wl_desc + ", inputs resident in HBM, labels left in HBM",
                 "frames_per_gpu_per_step": F, "batches_in_flight_per_gpu": n_streams,
                 "points_per_frame": int(total_pts // F),
-                "max_split_depth": 3, "max_iter": 100, "num_sectors": 10,
+                "max_split_depth": cfg_kw.get("max_split_depth", 1000), "max_iter": 100, "num_sectors": 10,
             },
             "ms_per_frame": round(1e3 * elapsed / (F * args.steps), 5),
             "single_frame_latency_ms": None if lat_ms is None else round(lat_ms, 4),
