@@ -148,6 +148,8 @@ def main():
                     help="c2 (default) is the configuration the metric is quoted on; the others are informational")
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (one batch); 0 = the workload's default (c2: 512)")
     ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (HIP streams, one engine each)")
+    ap.add_argument("--max-iter", type=int, default=100,
+                    help="refit iterations; 0 = SURVEY.md 8d 'variant B' (every fit ends at once, so the recursion is forced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-frame-latency", action="store_true",
                     help="also time batches of ONE frame (extra launches of the same kernels; off by default so that "
@@ -178,6 +180,8 @@ def main():
     wl_gen, cfg_kw, wl_frames, wl_desc = WORKLOADS[args.workload]      # c2 = configs[1]: recursion depth = 3
     if args.frames <= 0:
         args.frames = wl_frames
+    if args.max_iter != 100:
+        cfg_kw = dict(cfg_kw, max_iter=args.max_iter)
     frames = make_frames(args.frames, rank, args.workload)
     offsets = np.zeros(len(frames) + 1, np.uint32)
     offsets[1:] = np.cumsum([len(f) for f in frames])
@@ -319,7 +323,7 @@ def main():
                 "workload": wl_desc + ", inputs resident in HBM, labels left in HBM",
                 "frames_per_gpu_per_step": F, "batches_in_flight_per_gpu": n_streams,
                 "points_per_frame": int(total_pts // F),
-                "max_split_depth": cfg_kw.get("max_split_depth", 1000), "max_iter": 100, "num_sectors": 10,
+                "max_split_depth": cfg_kw.get("max_split_depth", 1000), "max_iter": cfg_kw.get("max_iter", 100), "num_sectors": 10,
             },
             "ms_per_frame": round(1e3 * elapsed / (F * args.steps), 5),
             "single_frame_latency_ms": None if lat_ms is None else round(lat_ms, 4),
