@@ -357,13 +357,18 @@ def main():
                                      "addends_per_frame": chain_addends_per_batch // F}
             bin_s = sum(kms_solo[k][0] / max(1, kms_solo[k][1]) for k in ("bin_tile", "scan_offsets")) * 1e-3
             achb = BYTES_PER_POINT_BIN * total_pts / bin_s / 1e9
+            tb1, tsrc1 = load_pmc_traffic("bin_tile", F)
+            tb2, _ = load_pmc_traffic("scan_offsets", F)
             out["roofline_binning"] = {"kernels": "bin_tile+scan_offsets", "bound": "hbm",
                                        "measured": "one stream, right after the timed region (in it these kernels queue "
                                                    "behind other streams' patch_fit waves)",
                                        "ms_per_launch": round(bin_s * 1e3, 4),
                                        "achieved": round(achb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": round(achb / HBM_PEAK_GBS, 5), "traffic": None,
-                                       "algorithmic_bytes_per_point": BYTES_PER_POINT_BIN}
+                                       "frac": round(achb / HBM_PEAK_GBS, 5),
+                                       "traffic": None if tb1 is None or tb2 is None else tb1 + tb2,
+                                       "traffic_source": tsrc1,
+                                       "algorithmic_bytes_per_point": BYTES_PER_POINT_BIN,
+                                       "algorithmic_bytes_per_launch": BYTES_PER_POINT_BIN * total_pts}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, cfg_kw)
         print(json.dumps(out), flush=True)
