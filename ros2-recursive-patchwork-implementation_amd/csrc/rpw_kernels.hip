@@ -136,6 +136,8 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
     const uint32_t wbase = t_local * kTilePoints + wave * kWavePoints;
     uint32_t* mycnt = wcnt + wave * p.PB;
 
+    constexpr int kRankSteps = 2;                                  // distinct classes of a row ranked one by one before the match-any path
+    const int class_bits = 32 - __clz(p.P + 3);                    // bits that tell the classes 0 .. P+3 apart
     // all of the wave's loads first (8 x 12 B per lane in flight), then the arithmetic
     const char* frame_bytes = reinterpret_cast<const char*>(p.xyz + fo);      // frames are < 4 GB (rpw_create checks)
     P3 q[kTileItems];
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
         // stable rank inside the wave's sub-tile: one step per distinct class of the row
         const unsigned long long vmask = ballot64(valid);
         unsigned long long rem = vmask;
-        while (rem) {
+        for (int steps = 0; rem && steps < kRankSteps; ++steps) {
             const int first = __ffsll((long long)rem) - 1;
             const int c0 = __builtin_amdgcn_readlane(cls[r], first);      // `first` is wave-uniform: no LDS round trip
             const bool same = cls[r] == c0;                                // (an out-of-range lane may match: its offset is never used)
@@ -180,6 +182,24 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
             loff[r] = same ? old + (uint32_t)mbcnt64(m) : loff[r];
             mycnt[c0] = old + (uint32_t)__popcll(m);                       // every lane stores the same value: no exec juggling
             rem &= ~m;
+        }
+        if (rem) {
+            // A row of a cloud in RANDOM point order holds dozens of classes: the lanes that are left find their class
+            // mates all at once, bit by bit of the class id (a match-any built from ballots), at a cost that does not
+            // depend on the number of classes. The first lane of every class bumps the wave's counter (distinct classes,
+            // distinct addresses) and hands the run start to its mates.
+            const bool todo = (rem >> lane) & 1ull;
+            unsigned long long mm = rem;
+            for (int b = 0; b < class_bits; ++b) {
+                const bool bit = (cls[r] >> b) & 1;
+                const unsigned long long bb = ballot64(bit);
+                mm &= bit ? bb : ~bb;
+            }
+            const uint32_t rank = (uint32_t)mbcnt64(mm);
+            uint32_t run = 0;
+            if (todo && rank == 0) { run = mycnt[cls[r]]; mycnt[cls[r]] = run + (uint32_t)__popcll(mm); }
+            run = (uint32_t)__shfl((int)run, __ffsll((long long)mm) - 1);
+            loff[r] = todo ? run + rank : loff[r];
         }
     }
     __syncthreads();
