@@ -15,5 +15,6 @@ python3 bench.py --no-cpu-baseline --frames 1 --streams 1 --steps 200 --warmup 2
 # 3. rocprofv3 kernel statistics of the same default command, and of the binning probe
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_bench" -o t -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$ROOT/$OUT/bench_under_rocprof.json" 2> "$ROOT/$OUT/stats_bench.err" )
 ( cd /tmp && export TMPDIR=/tmp MAX_ITER=1 && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_c5" -o t -- python3 "$ROOT/tools/binning_probe.py" > "$ROOT/$OUT/binning_probe_c5x32.json" 2> "$ROOT/$OUT/stats_c5.err" )
+python3 tools/trace_phase_avg.py "$OUT/stats_bench/t_kernel_trace.csv" 6 18 > "$OUT/bench_kernel_trace_summary.json"   # 3 set-up + 3 warm-up launches precede the 18 timed ones
 find "$OUT" -name "*kernel_stats.csv" | sort
 tail -c 600 "$OUT/bench_default.json"
