@@ -86,3 +86,16 @@ def test_pointcloud2_io_cpp(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(rpw_amd.PKG_DIR, "cpp"),
                            os.path.join(ROOT, "tests", "cpp", "test_pointcloud2_io.cpp"), "-o", exe])
     assert "pointcloud2_io OK" in subprocess.check_output([exe], text=True)
+
+
+def test_exact_block_sum_prototype_matches_sequential_sums(tmp_path):
+    """tools/proto/exact_block_sum.cpp (groundwork, not product code): the parallel evaluation of a sequential binary32
+    sum -- integer prefix sum inside one binade, ties resolved in order, restart behind a binade change -- must equal the
+    real sequential sum bit for bit on its whole adversarial data set (the program exits non-zero on a mismatch)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "exact_block_sum"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-o", str(exe), os.path.join(root, "tools", "proto", "exact_block_sum.cpp")],
+                   check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert "MISMATCHES 0" in out and "resume strategy mismatches: 0" in out
