@@ -202,6 +202,7 @@ def main():
     stream = streams[0]
     F = len(frames)
     gather_in = torch.zeros(F, dtype=torch.int32, device=dev)
+    gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     step_no = [0]
 
     def step():
@@ -210,8 +211,10 @@ def main():
         engines[k].segment_batch_device(d_xyz.data_ptr(), offsets, d_labels_all[k].data_ptr(), None,
                                         streams[k].cuda_stream)
         if world > 1:
-            # trivial result gather: ground-point count per frame (RCCL all-gather of F int32 per rank)
-            gather_counts(gather_in, world)
+            # trivial result gather: ground-point count per frame (RCCL all-gather of F int32 per rank), on a stream
+            # of its own: issued on a batch's stream it would make that stream's next batch wait for the collective
+            with torch.cuda.stream(gather_stream):
+                gather_counts(gather_in, world)
 
     # set-up, not a step: every engine (one per stream) runs once so that its first-call costs (lazy buffers, code
     # object load) are paid before the W warm-up steps, whatever W is
