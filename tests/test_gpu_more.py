@@ -358,3 +358,30 @@ def test_batch_mixing_a_huge_frame_with_small_ones(engine_factory):
     for f, xyz in enumerate(frames):
         sl = slice(int(off[f]), int(off[f + 1]))
         assert_frame_parity(xyz, L[sl], None, {k: st[k][f] for k in st.dtype.names}, None, oc, check_nodes=False, tag=f"mixed-frame{f}")
+
+
+def test_large_batch_equals_frames_processed_alone(engine_factory):
+    """Size-independent property at bench scale: in a batch of 96 HDL-64 frames (12 M points, one launch) every frame
+    gets exactly the labels and stats it gets when it is processed alone; three of them are also checked against the
+    oracle. Exercises frame_of_tile, per-frame class totals and the size-bucket lists with thousands of patches."""
+    import torch
+    import bench
+    frames = bench.make_frames(96, 0)
+    pc, oc = cfg_pair(max_split_depth=3)
+    off = np.zeros(len(frames) + 1, np.uint32); off[1:] = np.cumsum([len(f) for f in frames]); N = int(off[-1])
+    big = engine_factory(pc, max_points=N, max_frames=len(frames))
+    d = torch.from_numpy(np.concatenate(frames)).cuda()
+    lab = torch.empty(N, dtype=torch.uint8, device="cuda")
+    big.segment_batch_device(d.data_ptr(), off, lab.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = big.batch_stats(len(frames)); L = lab.cpu().numpy()
+    one = engine_factory(pc, max_points=max(len(f) for f in frames), max_frames=1)
+    for f in range(0, len(frames), 5):
+        l1, _, s1 = one.segment(frames[f])
+        sl = slice(int(off[f]), int(off[f + 1]))
+        assert np.array_equal(L[sl], l1), f"frame {f}: batch labels differ from the frame processed alone"
+        for k in ("n_zone", "n_ground", "n_patches", "n_nodes", "n_splits", "total_iterations"):
+            assert int(st[k][f]) == int(s1[k]), (f, k)
+    for f in (0, 47, 95):
+        sl = slice(int(off[f]), int(off[f + 1]))
+        assert_frame_parity(frames[f], L[sl], None, {k: st[k][f] for k in st.dtype.names}, None, oc, check_nodes=False, tag=f"batch96-frame{f}")
