@@ -3,9 +3,11 @@
 //   K1 bin_tile        cleanPoints + computeDistances2D + filterPointsByRadius + computeAngles +
 //                      patch membership (recursive_patchwork.cpp:315-378), O(N) instead of O(P*N),
 //                      and a stable tile-local sort: points grouped by patch inside each 2048-point tile
-//   K2 scan_offsets    per-frame exclusive offsets (patch-major, then tile order = input order)
-//   K3 patch_fit       gather of the patch's runs (recursive_patchwork.cpp:372-378: patch_points in zone
-//                      order), then fitPlaneAndSplit / fitPlanePCA / computeCentroid / computeCovariance /
+//                      (+ the frame's class totals, added up tile by tile with integer atomics)
+//   K2 scan_offsets    per frame: one scan over the classes -> patch begins, patch descriptors, size-bucket lists
+//                      (frames of more than kGatherTiles tiles: also the tile-order offsets of every run)
+//   K3 patch_fit       scan of the patch's run lengths + gather of its runs (recursive_patchwork.cpp:372-378:
+//                      patch_points in zone order), then fitPlaneAndSplit / fitPlanePCA / computeCentroid / computeCovariance /
 //                      Eigen solve / computePlaneDistances / mask compare / split + recursion
 //                      (recursive_patchwork.cpp:77-308), one two-wave workgroup per (frame, patch)
 //
