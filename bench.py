@@ -164,6 +164,14 @@ def main():
     import torch.distributed as dist
     import rpw_amd
 
+    if not os.path.exists(rpw_amd.LIB_PATH):          # a snapshot without built artefacts: compile in-tree first
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            rpw_amd.build()
+        else:                                         # the other ranks of the node wait for local rank 0's build
+            t_wait = time.time()
+            while not os.path.exists(rpw_amd.LIB_PATH) and time.time() - t_wait < 600:
+                time.sleep(1.0)
+            time.sleep(2.0)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

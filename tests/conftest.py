@@ -39,6 +39,8 @@ def has_gpu():
 def engine_factory():
     """Creates rpw engines; the HIP library must exist -- no fallback."""
     import rpw_amd
+    if not os.path.exists(rpw_amd.LIB_PATH):          # a snapshot without built artefacts: compile in-tree (hipcc), then load
+        rpw_amd.build()
 
     made = []
 
