@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define RPW_ABI_VERSION 1
+#define RPW_ABI_VERSION 2
 
 typedef enum rpw_status {
     RPW_OK              = 0,
@@ -46,7 +46,8 @@ typedef enum rpw_status {
     RPW_ERR_NO_DEVICE   = 2,  /* no usable HIP device / kernels not loadable             */
     RPW_ERR_HIP         = 3,  /* a HIP runtime call failed (message has the HIP string)  */
     RPW_ERR_CAPACITY    = 4,  /* batch exceeds the capacity given to rpw_create          */
-    RPW_ERR_UNSUPPORTED = 5   /* config outside the supported range (num_sectors > 128)  */
+    RPW_ERR_UNSUPPORTED = 5,  /* config outside the supported range (num_sectors > 128)  */
+    RPW_ERR_BUSY        = 6   /* rpw_submit on a pipeline slot whose frame has not been rpw_wait-ed */
 } rpw_status;
 
 /* Mirrors recursive_patchwork::PatchworkConfig field for field
@@ -152,6 +153,39 @@ rpw_status  rpw_segment_pointcloud2(rpw_handle* h, const uint8_t* data, uint32_t
                                     uint32_t off_x, uint32_t off_y, uint32_t off_z,
                                     uint8_t* labels, float* residual, rpw_frame_stats* stats);
 
+/* ---- Host-pointer PIPELINE: the drop-in path with K frames in flight -------------------------------------------
+ * Every caller of the reference holds one frame in host memory and calls filterGroundPoints once per frame
+ * (reference src/recursive_patchwork_node.cpp:61-108 per PointCloud2 message, src/main.cpp:268,286,
+ * test/test_recursive_patchwork.cpp:68,155). rpw_segment is that call, synchronous: one frame's latency (~1.5 ms on
+ * an HDL-64 frame, set by its longest sequential add chain) bounds it to a few hundred frames/s. The pipeline keeps
+ * K frames in flight instead: every slot owns a HIP stream, pinned staging for the frame and its results, and its own
+ * device workspace, so the host copies, the H2D / D2H transfers and the kernels of different slots overlap.
+ *
+ *   rpw_set_pipeline(h, K)            K slots (0 frees them); each takes the handle's max_points of capacity
+ *   rpw_submit(h, slot, xyz, n, f)    copies the frame into the slot's pinned buffer and enqueues H2D -> kernels ->
+ *                                     D2H on the slot's stream; returns at once. RPW_ERR_BUSY if the slot's previous
+ *                                     frame has not been waited for. flags: RPW_SUBMIT_RESIDUAL.
+ *   rpw_slot_input(h, slot)           the slot's pinned input buffer (max_points x 3 floats): a caller that fills it
+ *                                     in place and passes it to rpw_submit saves the host copy
+ *   rpw_poll(h, slot, &done)          non-blocking: has the slot's frame finished?
+ *   rpw_wait(h, slot, labels, residual, stats)   blocks until the slot's frame is done, copies its results out and
+ *                                     frees the slot. Slots complete independently and may be waited in any order.
+ * One thread drives a handle (as everywhere in this ABI); K is at most RPW_MAX_SLOTS.
+ * Streams need hardware queues of their own to overlap: the library sets GPU_MAX_HW_QUEUES=16 when it is loaded
+ * unless the variable is already set (ROCm reads it when the HIP runtime starts; its default of 4 makes slots share
+ * queues and serialise). */
+#define RPW_MAX_SLOTS 32
+#define RPW_SUBMIT_RESIDUAL 1u
+rpw_status  rpw_set_pipeline(rpw_handle* h, uint32_t n_slots);
+uint32_t    rpw_get_pipeline(const rpw_handle* h);
+float*      rpw_slot_input(rpw_handle* h, uint32_t slot);
+rpw_status  rpw_submit(rpw_handle* h, uint32_t slot, const float* xyz, uint32_t n, uint32_t flags);
+/* the same on PointCloud2 message bytes (see rpw_segment_pointcloud2): what the ROS2 node submits */
+rpw_status  rpw_submit_pointcloud2(rpw_handle* h, uint32_t slot, const uint8_t* data, uint32_t n, uint32_t point_step,
+                                   uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t flags);
+rpw_status  rpw_poll(rpw_handle* h, uint32_t slot, int* done);
+rpw_status  rpw_wait(rpw_handle* h, uint32_t slot, uint8_t* labels, float* residual, rpw_frame_stats* stats);
+
 /* ---- LidarFusion pre-step, fused into the binning kernel's load stage --------------------------------------
  * reference src/recursive_patchwork/src/lidar_fusion.cpp:42-86 (fuseLidarPointClouds), :88-107 (processSingleLidar),
  * :109-126 (applyRotation2D), :148-159 + :184-187 (removeEgoVehicle). A frame is then the concatenation of the
@@ -177,7 +211,9 @@ rpw_status  rpw_segment_batch_device_fused(rpw_handle* h, const float* d_xyz, co
  *   frame_offsets  HOST array of n_frames + 1 point offsets (frame f = [off[f], off[f+1]))
  *   d_labels       device pointer, off[n_frames] bytes
  *   d_residual     device pointer or NULL
- * Returns after enqueueing; results are valid once `stream` has completed. */
+ * Returns after enqueueing; results are valid once `stream` has completed. The handle's workspace holds ONE batch
+ * at a time: a call on a different stream than the previous one first makes that stream wait (on the device) for
+ * the previous batch, so two batches never share scratch memory; use one handle per batch in flight to overlap. */
 rpw_status  rpw_segment_batch_device(rpw_handle* h, const float* d_xyz, const uint32_t* frame_offsets,
                                      uint32_t n_frames, uint8_t* d_labels, float* d_residual,
                                      void* stream);

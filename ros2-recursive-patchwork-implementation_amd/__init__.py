@@ -123,6 +123,20 @@ def load_library():
     L.rpw_segment.restype = i32
     L.rpw_segment_pointcloud2.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, vp, C.POINTER(CFrameStats)]
     L.rpw_segment_pointcloud2.restype = i32
+    L.rpw_set_pipeline.argtypes = [vp, u32]
+    L.rpw_set_pipeline.restype = i32
+    L.rpw_get_pipeline.argtypes = [vp]
+    L.rpw_get_pipeline.restype = u32
+    L.rpw_slot_input.argtypes = [vp, u32]
+    L.rpw_slot_input.restype = vp
+    L.rpw_submit.argtypes = [vp, u32, vp, u32, u32]
+    L.rpw_submit.restype = i32
+    L.rpw_submit_pointcloud2.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, u32]
+    L.rpw_submit_pointcloud2.restype = i32
+    L.rpw_poll.argtypes = [vp, u32, C.POINTER(i32)]
+    L.rpw_poll.restype = i32
+    L.rpw_wait.argtypes = [vp, u32, vp, vp, C.POINTER(CFrameStats)]
+    L.rpw_wait.restype = i32
     L.rpw_set_sensors.argtypes = [vp, u32, vp]
     L.rpw_set_sensors.restype = i32
     L.rpw_segment_fused.argtypes = [vp, vp, vp, vp, vp, C.POINTER(CFrameStats)]
@@ -153,7 +167,8 @@ def load_library():
 
 EXPORTED_SYMBOLS = (
     "rpw_default_config", "rpw_abi_version", "rpw_create", "rpw_destroy", "rpw_set_config", "rpw_get_config",
-    "rpw_last_error", "rpw_segment", "rpw_segment_pointcloud2", "rpw_set_sensors", "rpw_segment_fused",
+    "rpw_last_error", "rpw_segment", "rpw_segment_pointcloud2", "rpw_set_pipeline", "rpw_get_pipeline", "rpw_slot_input",
+    "rpw_submit", "rpw_submit_pointcloud2", "rpw_poll", "rpw_wait", "rpw_set_sensors", "rpw_segment_fused",
     "rpw_segment_batch_device_fused", "rpw_segment_batch_device", "rpw_get_batch_stats", "rpw_set_trace",
     "rpw_get_nodes", "rpw_set_profiling", "rpw_get_kernel_ms", "rpw_debug_angles", "rpw_debug_eig3",
     "rpw_debug_angles_host",
@@ -229,6 +244,50 @@ class Engine:
         self._check(self._L.rpw_segment_pointcloud2(self._h, data.ctypes.data, n, point_step, off_x, off_y, off_z,
                                                     labels.ctypes.data, res.ctypes.data if res is not None else None,
                                                     C.byref(st)))
+        return labels, res, {k: getattr(st, k) for k, _ in CFrameStats._fields_}
+
+    # ---- host-pointer pipeline (rpw_submit / rpw_wait): K frames in flight, one slot each ----
+    def set_pipeline(self, n_slots: int):
+        self._check(self._L.rpw_set_pipeline(self._h, n_slots))
+        self._slot_n = [0] * n_slots
+        self._slot_res = [False] * n_slots
+
+    def slot_input(self, slot: int, n: int) -> np.ndarray:
+        """The slot's pinned input buffer as an (n, 3) float32 view: fill it and pass it to submit() to skip the host copy."""
+        ptr = self._L.rpw_slot_input(self._h, slot)
+        if not ptr:
+            raise RpwError(f"slot {slot} does not exist")
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n, 3))
+
+    def submit(self, slot: int, xyz: np.ndarray, want_residual: bool = False):
+        """Enqueue one frame (host memory) on a pipeline slot; returns at once."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        self._check(self._L.rpw_submit(self._h, slot, xyz.ctypes.data, len(xyz), 1 if want_residual else 0))
+        self._slot_n[slot] = len(xyz)
+        self._slot_res[slot] = want_residual
+
+    def submit_pointcloud2(self, slot: int, data: np.ndarray, n: int, point_step: int, off_x: int, off_y: int, off_z: int,
+                           want_residual: bool = False):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        self._check(self._L.rpw_submit_pointcloud2(self._h, slot, data.ctypes.data, n, point_step, off_x, off_y, off_z,
+                                                   1 if want_residual else 0))
+        self._slot_n[slot] = n
+        self._slot_res[slot] = want_residual
+
+    def poll(self, slot: int) -> bool:
+        done = C.c_int(0)
+        self._check(self._L.rpw_poll(self._h, slot, C.byref(done)))
+        return bool(done.value)
+
+    def wait(self, slot: int, labels: np.ndarray | None = None):
+        """Block until the slot's frame is done -> (labels, residual | None, stats dict); frees the slot."""
+        n = self._slot_n[slot]
+        if labels is None:
+            labels = np.empty(n, np.uint8)
+        res = np.empty(n, np.float32) if self._slot_res[slot] else None
+        st = CFrameStats()
+        self._check(self._L.rpw_wait(self._h, slot, labels.ctypes.data, res.ctypes.data if res is not None else None,
+                                     C.byref(st)))
         return labels, res, {k: getattr(st, k) for k, _ in CFrameStats._fields_}
 
     def set_sensors(self, rotation_deg, ego_radius):

@@ -20,11 +20,61 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// Streams overlap only when they sit on hardware queues of their own; ROCm reads this knob when the HIP runtime
+// starts (default 4). Never overrides a value the user has set.
+__attribute__((constructor)) void rpw_runtime_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 constexpr int kStageSlots = 8;
 
 struct EventPair { int kernel; hipEvent_t a, b; };
 
 } // namespace
+
+// Everything one batch in flight needs on the device: a handle owns one for the batch / one-frame calls and one
+// per pipeline slot (rpw_submit / rpw_wait), so that frames in flight never share scratch memory.
+struct Workspace {
+    uint32_t max_points = 0, max_frames = 0, max_tiles = 0;
+    uint32_t* d_offsets = nullptr;       // [2*(F+1)] frame_off then tile_base, then [F][kMaxSensors+1] sensor offsets
+    uint32_t* h_offsets[kStageSlots] = {};   // pinned staging ring
+    hipEvent_t stage_ev[kStageSlots] = {};
+    bool stage_used[kStageSlots] = {};
+    int stage_next = 0;
+
+    uint32_t* d_hist = nullptr;
+    uint32_t* d_patch_begin = nullptr;
+    PatchDesc* d_patches = nullptr;
+    uint32_t* d_ctrl = nullptr;          // [kBuckets] bucket counts + [1] node count (+pad), then [F][PB] class totals of every frame
+    uint32_t* d_bucket_list = nullptr;
+    float *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr, *d_ax = nullptr, *d_ay = nullptr, *d_az = nullptr;
+    float4* d_tp = nullptr;
+    uint32_t* d_tdir = nullptr;
+    uint32_t* d_sidx = nullptr;
+    uint8_t* d_mask = nullptr;
+    rpw_frame_stats* d_stats = nullptr;
+
+    // the batch in flight on this workspace: its stream, its size, and an event recorded behind its last kernel
+    hipStream_t last_stream = nullptr;
+    uint32_t last_frames = 0;
+    hipEvent_t done_ev = nullptr;
+    bool done_valid = false;
+};
+
+// One frame in flight through the host-pointer pipeline (rpw_submit / rpw_wait).
+struct Slot {
+    Workspace ws;
+    hipStream_t stream = nullptr;
+    unsigned char* h_in = nullptr;       // pinned, device-readable: the frame as the caller handed it over (read in place by bin_tile)
+    size_t h_in_bytes = 0;
+    uint8_t* h_labels = nullptr;         // pinned
+    uint8_t* d_labels = nullptr;
+    float* h_res = nullptr;              // pinned, allocated on first use
+    float* d_res = nullptr;
+    rpw_frame_stats* h_stats = nullptr;  // pinned
+    hipEvent_t done = nullptr;
+    bool pending = false;
+    bool want_residual = false;
+    uint32_t n = 0;
+};
 
 struct rpw_handle {
     rpw_config cfg;
@@ -40,25 +90,8 @@ struct rpw_handle {
     // LidarFusion pre-step (off when sensors.n == 0)
     SensorTable sensors;
 
-    // batch buffers
-    uint32_t* d_offsets = nullptr;       // [2*(F+1)] frame_off then tile_base, then [F][kMaxSensors+1] sensor offsets
-    uint32_t* h_offsets[kStageSlots] = {};   // pinned staging ring
-    hipEvent_t stage_ev[kStageSlots] = {};
-    bool stage_used[kStageSlots] = {};
-    int stage_next = 0;
-
-    uint32_t* d_hist = nullptr;
-    uint32_t max_tiles = 0;
-    uint32_t* d_patch_begin = nullptr;
-    PatchDesc* d_patches = nullptr;
-    uint32_t* d_ctrl = nullptr;          // [kBuckets] bucket counts + [1] node count (+pad), then [F][PB] class totals of every frame
-    uint32_t* d_bucket_list = nullptr;
-    float *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr, *d_ax = nullptr, *d_ay = nullptr, *d_az = nullptr;
-    float4* d_tp = nullptr;
-    uint32_t* d_tdir = nullptr;
-    uint32_t* d_sidx = nullptr;
-    uint8_t* d_mask = nullptr;
-    rpw_frame_stats* d_stats = nullptr;
+    Workspace ws;                        // batch / one-frame calls
+    std::vector<Slot*> slots;            // host-pointer pipeline
 
     // trace
     int trace = 0;
@@ -72,10 +105,6 @@ struct rpw_handle {
     size_t raw_bytes = 0;
     uint8_t* d_labels = nullptr;
     float* d_res = nullptr;
-
-    // last batch
-    hipStream_t last_stream = nullptr;
-    uint32_t last_frames = 0;
 
     // profiling
     int profiling = 0;
@@ -99,18 +128,45 @@ rpw_status fail(rpw_handle* h, rpw_status st, const char* fmt, ...)
     do { hipError_t e_ = (call);                                                                  \
          if (e_ != hipSuccess) return fail((h), RPW_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
+void free_workspace(Workspace& w)
+{
+    auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    F(w.d_offsets); F(w.d_hist); F(w.d_patch_begin); F(w.d_patches);
+    F(w.d_ctrl); F(w.d_bucket_list); F(w.d_sx); F(w.d_sy); F(w.d_sz); F(w.d_ax); F(w.d_ay); F(w.d_az);
+    F(w.d_sidx); F(w.d_mask); F(w.d_tp); F(w.d_tdir); F(w.d_stats);
+    for (int i = 0; i < kStageSlots; ++i) {
+        if (w.h_offsets[i]) { (void)hipHostFree(w.h_offsets[i]); w.h_offsets[i] = nullptr; }
+        if (w.stage_ev[i]) { (void)hipEventDestroy(w.stage_ev[i]); w.stage_ev[i] = nullptr; }
+        w.stage_used[i] = false;
+    }
+    if (w.done_ev) { (void)hipEventDestroy(w.done_ev); w.done_ev = nullptr; }
+    w.done_valid = false; w.last_stream = nullptr; w.last_frames = 0;
+}
+
+void free_slot(Slot* s)
+{
+    if (!s) return;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    free_workspace(s->ws);
+    if (s->h_in) (void)hipHostFree(s->h_in);
+    if (s->h_labels) (void)hipHostFree(s->h_labels);
+    if (s->d_labels) (void)hipFree(s->d_labels);
+    if (s->h_res) (void)hipHostFree(s->h_res);
+    if (s->d_res) (void)hipFree(s->d_res);
+    if (s->h_stats) (void)hipHostFree(s->h_stats);
+    if (s->done) (void)hipEventDestroy(s->done);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
 void free_device(rpw_handle* h)
 {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(h->d_bounds); F(h->d_offsets); F(h->d_hist); F(h->d_patch_begin); F(h->d_patches);
-    F(h->d_ctrl); F(h->d_bucket_list); F(h->d_sx); F(h->d_sy); F(h->d_sz); F(h->d_ax); F(h->d_ay); F(h->d_az);
-    F(h->d_sidx); F(h->d_mask); F(h->d_tp); F(h->d_tdir); F(h->d_stats); F(h->d_nodes); F(h->d_in); F(h->d_raw); F(h->d_labels); F(h->d_res);
+    for (Slot* s : h->slots) free_slot(s);
+    h->slots.clear();
+    free_workspace(h->ws);
+    F(h->d_bounds); F(h->d_nodes); F(h->d_in); F(h->d_raw); F(h->d_labels); F(h->d_res);
     h->raw_bytes = 0;
-    for (int i = 0; i < kStageSlots; ++i) {
-        if (h->h_offsets[i]) { (void)hipHostFree(h->h_offsets[i]); h->h_offsets[i] = nullptr; }
-        if (h->stage_ev[i]) { (void)hipEventDestroy(h->stage_ev[i]); h->stage_ev[i] = nullptr; }
-        h->stage_used[i] = false;
-    }
 }
 
 rpw_status validate_config(rpw_handle* h, const rpw_config* c)
@@ -166,8 +222,60 @@ void build_tables(const rpw_config& c, PolarTables& t, std::vector<float>& bound
     for (int k = 0; k <= c.num_sectors; ++k) bounds[k] = k * sector_angle;
 }
 
+// device buffers of one workspace: N points / F frames of capacity
+rpw_status alloc_workspace(rpw_handle* h, Workspace& w, size_t N, size_t F)
+{
+    free_workspace(w);
+    if (N == 0) N = 1;
+    if (F == 0) F = 1;
+    w.max_points = (uint32_t)N; w.max_frames = (uint32_t)F;
+    const size_t off_words = 2 * (F + 1) + F * (kMaxSensors + 1);
+    RPW_HIP(h, hipMalloc(&w.d_offsets, off_words * sizeof(uint32_t)));
+    for (int i = 0; i < kStageSlots; ++i) {
+        RPW_HIP(h, hipHostMalloc((void**)&w.h_offsets[i], off_words * sizeof(uint32_t), hipHostMallocDefault));
+        RPW_HIP(h, hipEventCreateWithFlags(&w.stage_ev[i], hipEventDisableTiming));
+    }
+    RPW_HIP(h, hipEventCreateWithFlags(&w.done_ev, hipEventDisableTiming));
+    w.max_tiles = (uint32_t)(N / kTilePoints + F);
+    RPW_HIP(h, hipMalloc(&w.d_hist, (size_t)w.max_tiles * h->PB * sizeof(uint32_t)));
+    RPW_HIP(h, hipMalloc(&w.d_patch_begin, F * (size_t)(h->P + 1) * sizeof(uint32_t)));
+    RPW_HIP(h, hipMalloc(&w.d_patches, F * (size_t)h->P * sizeof(PatchDesc)));
+    RPW_HIP(h, hipMalloc(&w.d_ctrl, (kBuckets + 4 + F * (size_t)h->PB) * sizeof(uint32_t)));     // + per-frame class totals
+    RPW_HIP(h, hipMalloc(&w.d_bucket_list, (size_t)kBuckets * F * h->P * sizeof(uint32_t)));
+    RPW_HIP(h, hipMalloc(&w.d_sx, N * sizeof(float)));
+    RPW_HIP(h, hipMalloc(&w.d_sy, N * sizeof(float)));
+    RPW_HIP(h, hipMalloc(&w.d_sz, N * sizeof(float)));
+    RPW_HIP(h, hipMalloc(&w.d_ax, N * sizeof(float)));
+    RPW_HIP(h, hipMalloc(&w.d_ay, N * sizeof(float)));
+    RPW_HIP(h, hipMalloc(&w.d_az, N * sizeof(float)));
+    RPW_HIP(h, hipMalloc(&w.d_sidx, N * sizeof(uint32_t)));
+    {   // tile-sorted records: slot < frame offset + frame size, so N records suffice
+        RPW_HIP(h, hipMalloc(&w.d_tp, N * sizeof(float4)));
+        RPW_HIP(h, hipMalloc(&w.d_tdir, (size_t)w.max_tiles * h->PB * sizeof(uint32_t)));
+    }
+    RPW_HIP(h, hipMalloc(&w.d_mask, N));
+    RPW_HIP(h, hipMalloc(&w.d_stats, F * sizeof(rpw_frame_stats)));
+    return RPW_OK;
+}
+
+rpw_status alloc_slot(rpw_handle* h, Slot* s)
+{
+    const size_t N = h->max_points ? h->max_points : 1;
+    rpw_status st = alloc_workspace(h, s->ws, N, 1);
+    if (st != RPW_OK) return st;
+    RPW_HIP(h, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    RPW_HIP(h, hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+    s->h_in_bytes = N * 3 * sizeof(float);
+    RPW_HIP(h, hipHostMalloc((void**)&s->h_in, s->h_in_bytes, hipHostMallocDefault));
+    RPW_HIP(h, hipHostMalloc((void**)&s->h_labels, N, hipHostMallocDefault));
+    RPW_HIP(h, hipMalloc((void**)&s->d_labels, N));
+    RPW_HIP(h, hipHostMalloc((void**)&s->h_stats, sizeof(rpw_frame_stats), hipHostMallocDefault));
+    return RPW_OK;
+}
+
 rpw_status allocate(rpw_handle* h)
 {
+    const size_t n_slots = h->slots.size();
     free_device(h);
     const size_t N = h->max_points ? h->max_points : 1, F = h->max_frames ? h->max_frames : 1;
     h->S = h->cfg.num_sectors; h->P = 8 * h->S; h->PB = (h->P + 4 + 3) & ~3;       // patch classes + {no patch, outside, non-finite, ego-removed}
@@ -175,32 +283,16 @@ rpw_status allocate(rpw_handle* h)
     build_tables(h->cfg, h->tab, bounds);
     RPW_HIP(h, hipMalloc(&h->d_bounds, bounds.size() * sizeof(float)));
     RPW_HIP(h, hipMemcpy(h->d_bounds, bounds.data(), bounds.size() * sizeof(float), hipMemcpyHostToDevice));
-    const size_t off_words = 2 * (F + 1) + F * (kMaxSensors + 1);
-    RPW_HIP(h, hipMalloc(&h->d_offsets, off_words * sizeof(uint32_t)));
-    for (int i = 0; i < kStageSlots; ++i) {
-        RPW_HIP(h, hipHostMalloc((void**)&h->h_offsets[i], off_words * sizeof(uint32_t), hipHostMallocDefault));
-        RPW_HIP(h, hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
-    }
-    h->max_tiles = (uint32_t)(N / kTilePoints + F);
-    RPW_HIP(h, hipMalloc(&h->d_hist, (size_t)h->max_tiles * h->PB * sizeof(uint32_t)));
-    RPW_HIP(h, hipMalloc(&h->d_patch_begin, F * (size_t)(h->P + 1) * sizeof(uint32_t)));
-    RPW_HIP(h, hipMalloc(&h->d_patches, F * (size_t)h->P * sizeof(PatchDesc)));
-    RPW_HIP(h, hipMalloc(&h->d_ctrl, (kBuckets + 4 + F * (size_t)h->PB) * sizeof(uint32_t)));     // + per-frame class totals
-    RPW_HIP(h, hipMalloc(&h->d_bucket_list, (size_t)kBuckets * F * h->P * sizeof(uint32_t)));
-    RPW_HIP(h, hipMalloc(&h->d_sx, N * sizeof(float)));
-    RPW_HIP(h, hipMalloc(&h->d_sy, N * sizeof(float)));
-    RPW_HIP(h, hipMalloc(&h->d_sz, N * sizeof(float)));
-    RPW_HIP(h, hipMalloc(&h->d_ax, N * sizeof(float)));
-    RPW_HIP(h, hipMalloc(&h->d_ay, N * sizeof(float)));
-    RPW_HIP(h, hipMalloc(&h->d_az, N * sizeof(float)));
-    RPW_HIP(h, hipMalloc(&h->d_sidx, N * sizeof(uint32_t)));
-    {   // tile-sorted records: slot < frame offset + frame size, so N records suffice
-        RPW_HIP(h, hipMalloc(&h->d_tp, N * sizeof(float4)));
-        RPW_HIP(h, hipMalloc(&h->d_tdir, (size_t)h->max_tiles * h->PB * sizeof(uint32_t)));
-    }
-    RPW_HIP(h, hipMalloc(&h->d_mask, N));
-    RPW_HIP(h, hipMalloc(&h->d_stats, F * sizeof(rpw_frame_stats)));
+    rpw_status st = alloc_workspace(h, h->ws, N, F);
+    if (st != RPW_OK) return st;
     if (h->trace && h->nodes_cap) RPW_HIP(h, hipMalloc(&h->d_nodes, (size_t)h->nodes_cap * sizeof(rpw_node)));
+    for (size_t i = 0; i < n_slots; ++i) {           // a pipeline that existed before a re-allocation is rebuilt
+        Slot* s = new (std::nothrow) Slot();
+        if (!s) return fail(h, RPW_ERR_INVALID, "out of host memory");
+        h->slots.push_back(s);
+        st = alloc_slot(h, s);
+        if (st != RPW_OK) return st;
+    }
     return RPW_OK;
 }
 
@@ -208,7 +300,7 @@ hipEvent_t get_event(rpw_handle* h)
 {
     if (!h->free_events.empty()) { hipEvent_t e = h->free_events.back(); h->free_events.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
 
@@ -228,6 +320,11 @@ void timed(rpw_handle* h, int kernel, hipStream_t s, Launch launch)
 {
     if (!h->profiling) { launch(); return; }
     EventPair ep; ep.kernel = kernel; ep.a = get_event(h); ep.b = get_event(h);
+    if (!ep.a || !ep.b) {                        // no event to be had: run the kernel untimed rather than not at all
+        if (ep.a) h->free_events.push_back(ep.a);
+        if (ep.b) h->free_events.push_back(ep.b);
+        launch(); return;
+    }
     (void)hipEventRecord(ep.a, s);
     launch();
     (void)hipEventRecord(ep.b, s);
@@ -237,68 +334,90 @@ void timed(rpw_handle* h, int kernel, hipStream_t s, Launch launch)
 
 struct InputLayout { uint32_t stride = 12, off[3] = {0, 4, 8}; };
 
-rpw_status run_batch(rpw_handle* h, const void* d_xyz, const uint32_t* frame_offsets, uint32_t n_frames,
+// kernel parameters of one batch on workspace w
+void fill_params(rpw_handle* h, Workspace& w, DevParams& p, const void* d_xyz, uint32_t F, uint32_t tiles, uint8_t* d_labels,
+                 float* d_residual, const InputLayout& lay, int ns)
+{
+    p.cfg = h->cfg; p.tab = h->tab; p.bounds = h->d_bounds; p.S = h->S; p.P = h->P; p.PB = h->PB;
+    p.n_frames = F; p.n_tiles = tiles; p.frame_first = 0; p.frame_count = F; p.tile_first = 0; p.tile_count = tiles; p.frame_off = w.d_offsets; p.tile_base = w.d_offsets + (F + 1);
+    p.xyz = reinterpret_cast<const P3*>(d_xyz); p.in_stride = lay.stride;
+    p.in_off[0] = lay.off[0]; p.in_off[1] = lay.off[1]; p.in_off[2] = lay.off[2]; p.labels = d_labels;
+    p.sensors = h->sensors; if (ns == 0) p.sensors.n = 0;
+    p.sensor_off = w.d_offsets + 2 * (F + 1); p.residual = d_residual;
+    p.hist = w.d_hist; p.ftot = w.d_ctrl + kBuckets + 4; p.patch_begin = w.d_patch_begin; p.patches = w.d_patches;
+    p.bucket_count = w.d_ctrl; p.bucket_list = w.d_bucket_list; p.list_stride = w.max_frames * (uint32_t)h->P;
+    p.tp = w.d_tp; p.tdir = w.d_tdir;
+    p.sx = w.d_sx; p.sy = w.d_sy; p.sz = w.d_sz; p.sidx = w.d_sidx; p.ax = w.d_ax; p.ay = w.d_ay; p.az = w.d_az;
+    p.mask = w.d_mask; p.stats = w.d_stats;
+    // the trace buffer belongs to the handle: only its own workspace writes it
+    const bool tracing = (&w == &h->ws) && h->trace && h->d_nodes;
+    p.trace = tracing ? 1 : 0; p.nodes = tracing ? h->d_nodes : nullptr; p.node_count = w.d_ctrl + kBuckets; p.nodes_cap = tracing ? h->nodes_cap : 0;
+
+}
+
+rpw_status run_batch(rpw_handle* h, Workspace& w, const void* d_xyz, const uint32_t* frame_offsets, uint32_t n_frames,
                      uint8_t* d_labels, float* d_residual, hipStream_t stream, const InputLayout& lay = InputLayout(),
                      const uint32_t* sensor_offsets = nullptr /* [F][sensors.n + 1], frame-relative */)
 {
     if (!frame_offsets) return fail(h, RPW_ERR_INVALID, "frame_offsets is null");
-    if (n_frames > h->max_frames) return fail(h, RPW_ERR_CAPACITY, "n_frames %u > capacity %u", n_frames, h->max_frames);
-    h->last_stream = stream; h->last_frames = n_frames;
-    if (n_frames == 0) return RPW_OK;
+    if (n_frames > w.max_frames) return fail(h, RPW_ERR_CAPACITY, "n_frames %u > capacity %u", n_frames, w.max_frames);
+    if (n_frames == 0) {
+        // an empty batch touches nothing: it completes at once, whatever ran before
+        w.last_stream = stream; w.last_frames = 0; w.done_valid = false;
+        return RPW_OK;
+    }
     const uint32_t total = frame_offsets[n_frames];
-    if (total > h->max_points) return fail(h, RPW_ERR_CAPACITY, "batch of %u points > capacity %u", total, h->max_points);
+    if (total > w.max_points) return fail(h, RPW_ERR_CAPACITY, "batch of %u points > capacity %u", total, w.max_points);
     if (total && (!d_xyz || !d_labels)) return fail(h, RPW_ERR_INVALID, "null device pointer");
     RPW_HIP(h, hipSetDevice(h->device));
 
-    const int slot = h->stage_next; h->stage_next = (h->stage_next + 1) % kStageSlots;
-    if (h->stage_used[slot]) RPW_HIP(h, hipEventSynchronize(h->stage_ev[slot]));
-    uint32_t* ho = h->h_offsets[slot];
+    // ---- validate everything on the host before anything is enqueued ------------------------------------------
     const uint32_t F = n_frames;
+    if (frame_offsets[0] != 0) return fail(h, RPW_ERR_INVALID, "frame_offsets[0] must be 0");
     uint32_t tiles = 0;
+    for (uint32_t f = 0; f < F; ++f) {
+        if (frame_offsets[f + 1] < frame_offsets[f]) return fail(h, RPW_ERR_INVALID, "frame_offsets not monotone");
+        const uint32_t nf = frame_offsets[f + 1] - frame_offsets[f];
+        if ((uint64_t)nf * 16u > 0xffffffffull)      // bin_tile addresses a frame's records with 32-bit byte offsets
+            return fail(h, RPW_ERR_CAPACITY, "frame %u has %u points; the limit is 268435455 per frame", f, nf);
+        tiles += (nf + kTilePoints - 1) / kTilePoints;
+    }
+    if (tiles > w.max_tiles) return fail(h, RPW_ERR_CAPACITY, "tile count %u > capacity %u", tiles, w.max_tiles);
+    const int ns = sensor_offsets ? h->sensors.n : 0;
+    for (uint32_t f = 0; ns > 0 && f < F; ++f) {
+        const uint32_t nf = frame_offsets[f + 1] - frame_offsets[f];
+        const uint32_t* src = sensor_offsets + (size_t)f * (ns + 1);
+        if (src[0] != 0 || src[ns] != nf) return fail(h, RPW_ERR_INVALID, "sensor offsets of frame %u must run from 0 to the frame size", f);
+        for (int j = 1; j <= ns; ++j)
+            if (src[j] < src[j - 1]) return fail(h, RPW_ERR_INVALID, "sensor offsets of frame %u not monotone", f);
+    }
+
+    // ---- the workspace is single-occupancy: a batch on ANOTHER stream first waits for the one in flight ------------
+    // (scratch buffers, control words and stats belong to the workspace; same-stream reuse is ordered by the stream)
+    if (w.done_valid && w.last_stream != stream) RPW_HIP(h, hipStreamWaitEvent(stream, w.done_ev, 0));
+
+    const int slot = w.stage_next; w.stage_next = (w.stage_next + 1) % kStageSlots;
+    if (w.stage_used[slot]) RPW_HIP(h, hipEventSynchronize(w.stage_ev[slot]));
+    uint32_t* ho = w.h_offsets[slot];
+    tiles = 0;
     for (uint32_t f = 0; f <= F; ++f) {
-        if (f && frame_offsets[f] < frame_offsets[f - 1]) return fail(h, RPW_ERR_INVALID, "frame_offsets not monotone");
         ho[f] = frame_offsets[f];
         ho[(F + 1) + f] = tiles;
         if (f < F) tiles += (frame_offsets[f + 1] - frame_offsets[f] + kTilePoints - 1) / kTilePoints;
     }
-    if (ho[0] != 0) return fail(h, RPW_ERR_INVALID, "frame_offsets[0] must be 0");
-    const int ns = sensor_offsets ? h->sensors.n : 0;
     size_t copy_words = 2 * (size_t)(F + 1);
     if (ns > 0) {
         uint32_t* so = ho + 2 * (F + 1);
-        for (uint32_t f = 0; f < F; ++f) {
-            const uint32_t nf = frame_offsets[f + 1] - frame_offsets[f];
-            const uint32_t* src = sensor_offsets + (size_t)f * (ns + 1);
-            if (src[0] != 0 || src[ns] != nf) return fail(h, RPW_ERR_INVALID, "sensor offsets of frame %u must run from 0 to the frame size", f);
-            for (int j = 0; j <= ns; ++j) {
-                if (j && src[j] < src[j - 1]) return fail(h, RPW_ERR_INVALID, "sensor offsets of frame %u not monotone", f);
-                so[(size_t)f * (ns + 1) + j] = src[j];
-            }
-        }
+        std::memcpy(so, sensor_offsets, (size_t)F * (ns + 1) * sizeof(uint32_t));
         copy_words += (size_t)F * (ns + 1);
     }
-    if (tiles > h->max_tiles) return fail(h, RPW_ERR_CAPACITY, "tile count %u > capacity %u", tiles, h->max_tiles);
-    for (uint32_t f = 0; f < F; ++f)      // bin_tile addresses a frame's records with 32-bit byte offsets
-        if ((uint64_t)(frame_offsets[f + 1] - frame_offsets[f]) * 16u > 0xffffffffull)
-            return fail(h, RPW_ERR_CAPACITY, "frame %u has %u points; the limit is 268435455 per frame", f, frame_offsets[f + 1] - frame_offsets[f]);
-    RPW_HIP(h, hipMemcpyAsync(h->d_offsets, ho, copy_words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    RPW_HIP(h, hipEventRecord(h->stage_ev[slot], stream));
-    h->stage_used[slot] = true;
-    RPW_HIP(h, hipMemsetAsync(h->d_ctrl, 0, (kBuckets + 4 + (size_t)F * h->PB) * sizeof(uint32_t), stream));
+    RPW_HIP(h, hipMemcpyAsync(w.d_offsets, ho, copy_words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    RPW_HIP(h, hipEventRecord(w.stage_ev[slot], stream));
+    w.stage_used[slot] = true;
+    RPW_HIP(h, hipMemsetAsync(w.d_ctrl, 0, (kBuckets + 4 + (size_t)F * h->PB) * sizeof(uint32_t), stream));
 
     DevParams p;
-    p.cfg = h->cfg; p.tab = h->tab; p.bounds = h->d_bounds; p.S = h->S; p.P = h->P; p.PB = h->PB;
-    p.n_frames = F; p.n_tiles = tiles; p.frame_first = 0; p.frame_count = F; p.tile_first = 0; p.tile_count = tiles; p.frame_off = h->d_offsets; p.tile_base = h->d_offsets + (F + 1);
-    p.xyz = reinterpret_cast<const P3*>(d_xyz); p.in_stride = lay.stride;
-    p.in_off[0] = lay.off[0]; p.in_off[1] = lay.off[1]; p.in_off[2] = lay.off[2]; p.labels = d_labels;
-    p.sensors = h->sensors; if (ns == 0) p.sensors.n = 0;
-    p.sensor_off = h->d_offsets + 2 * (F + 1); p.residual = d_residual;
-    p.hist = h->d_hist; p.ftot = h->d_ctrl + kBuckets + 4; p.patch_begin = h->d_patch_begin; p.patches = h->d_patches;
-    p.bucket_count = h->d_ctrl; p.bucket_list = h->d_bucket_list; p.list_stride = h->max_frames * (uint32_t)h->P;
-    p.tp = h->d_tp; p.tdir = h->d_tdir;
-    p.sx = h->d_sx; p.sy = h->d_sy; p.sz = h->d_sz; p.sidx = h->d_sidx; p.ax = h->d_ax; p.ay = h->d_ay; p.az = h->d_az;
-    p.mask = h->d_mask; p.stats = h->d_stats;
-    p.trace = (h->trace && h->d_nodes) ? 1 : 0; p.nodes = h->d_nodes; p.node_count = h->d_ctrl + kBuckets; p.nodes_cap = h->nodes_cap;
+    fill_params(h, w, p, d_xyz, F, tiles, d_labels, d_residual, lay, ns);
 
     // ---- binning pass: K1 and K2 once over the whole batch, then K3 ---------------------------------------------
     // (A variant that cut large batches into groups of frames and pipelined K1 / K2 over two streams, so that K3
@@ -307,6 +426,53 @@ rpw_status run_batch(rpw_handle* h, const void* d_xyz, const uint32_t* frame_off
     timed(h, RPW_K_SCAN, stream, [&] { launch_scan(p, stream); });
     timed(h, RPW_K_FIT, stream, [&] { launch_fit(p, stream); });
     RPW_HIP(h, hipGetLastError());
+    RPW_HIP(h, hipEventRecord(w.done_ev, stream));
+    w.done_valid = true; w.last_stream = stream; w.last_frames = n_frames;     // only a batch that was enqueued becomes "the last batch"
+    return RPW_OK;
+}
+
+// Layout check shared by every PointCloud2 entry: FLOAT32 x / y / z fields, 4-byte aligned, inside the record.
+// Written without additions that could wrap (off_x = 0xFFFFFFFC must not pass).
+bool pc2_layout_ok(uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z)
+{
+    if (point_step < 12 || (point_step & 3u)) return false;
+    const uint32_t last = point_step - 4;
+    return !(off_x & 3u) && !(off_y & 3u) && !(off_z & 3u) && off_x <= last && off_y <= last && off_z <= last;
+}
+
+Slot* get_slot(rpw_handle* h, uint32_t slot)
+{
+    return slot < h->slots.size() ? h->slots[slot] : nullptr;
+}
+
+// common tail of rpw_submit / rpw_submit_pointcloud2. The slot's stream receives KERNELS ONLY: the frame is read in
+// place from the slot's pinned buffer by the binning kernel (12 bytes per point over the host link, once) and the labels,
+// residuals and stats are written to the slot's pinned result buffers by a copy kernel. Copy-engine operations between
+// the kernels of different slots made the slots wait for each other (8 slots ran little faster than 2).
+rpw_status enqueue_slot(rpw_handle* h, Slot* s, uint32_t n, size_t bytes, const InputLayout& lay, bool want_residual)
+{
+    (void)bytes;
+    const size_t N = h->max_points ? h->max_points : 1;
+    if (want_residual && !s->d_res) {
+        RPW_HIP(h, hipMalloc((void**)&s->d_res, N * sizeof(float)));
+        RPW_HIP(h, hipHostMalloc((void**)&s->h_res, N * sizeof(float), hipHostMallocDefault));
+    }
+    hipStream_t st = s->stream;
+    Workspace& w = s->ws;
+    if ((uint64_t)n * 16u > 0xffffffffull) return fail(h, RPW_ERR_CAPACITY, "frame of %u points; the limit is 268435455 per frame", n);
+    const uint32_t tiles = (n + kTilePoints - 1) / kTilePoints;
+    if (tiles > w.max_tiles) return fail(h, RPW_ERR_CAPACITY, "tile count %u > capacity %u", tiles, w.max_tiles);
+    launch_frame_setup(w.d_offsets, n, tiles, w.d_ctrl, (uint32_t)(kBuckets + 4 + h->PB), st);
+    DevParams p;
+    fill_params(h, w, p, s->h_in, 1, tiles, s->d_labels, want_residual ? s->d_res : nullptr, lay, 0);
+    p.trace = 0; p.nodes = nullptr; p.nodes_cap = 0;
+    timed(h, RPW_K_BIN, st, [&] { launch_bin(p, st); });
+    timed(h, RPW_K_SCAN, st, [&] { launch_scan(p, st); });
+    timed(h, RPW_K_FIT, st, [&] { launch_fit(p, st); });
+    launch_frame_copy_out(s->d_labels, s->h_labels, n, want_residual ? s->d_res : nullptr, s->h_res, w.d_stats, s->h_stats, st);
+    RPW_HIP(h, hipGetLastError());
+    RPW_HIP(h, hipEventRecord(s->done, st));
+    s->pending = true; s->want_residual = want_residual; s->n = n;
     return RPW_OK;
 }
 
@@ -334,6 +500,8 @@ rpw_status rpw_create(const rpw_config* cfg, int device, uint32_t max_points, ui
     if (cfg) c = *cfg; else rpw_default_config(&c);
     rpw_status st = validate_config(nullptr, &c);
     if (st != RPW_OK) return st;
+    if (max_points > (1u << 30))      // patch_fit addresses its per-slot arrays with 32-bit byte offsets
+        return fail(nullptr, RPW_ERR_CAPACITY, "max_points %u > 1073741824", max_points);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -347,8 +515,6 @@ rpw_status rpw_create(const rpw_config* cfg, int device, uint32_t max_points, ui
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(nullptr, RPW_ERR_NO_DEVICE, "device %d is %s; kernels are built for gfx950 only", device, prop.gcnArchName);
     }
-    if (max_points > (1u << 30))      // patch_fit addresses its per-slot arrays with 32-bit byte offsets
-        return fail(nullptr, RPW_ERR_CAPACITY, "max_points %u > 1073741824", max_points);
     rpw_handle* h = new (std::nothrow) rpw_handle();
     if (!h) return fail(nullptr, RPW_ERR_INVALID, "out of host memory");
     std::memset(&h->sensors, 0, sizeof h->sensors);
@@ -401,16 +567,16 @@ rpw_status rpw_segment_batch_device(rpw_handle* h, const float* d_xyz, const uin
                                     uint8_t* d_labels, float* d_residual, void* stream)
 {
     if (!h) return RPW_ERR_INVALID;
-    return run_batch(h, d_xyz, frame_offsets, n_frames, d_labels, d_residual, (hipStream_t)stream);
+    return run_batch(h, h->ws, d_xyz, frame_offsets, n_frames, d_labels, d_residual, (hipStream_t)stream);
 }
 
 rpw_status rpw_get_batch_stats(rpw_handle* h, rpw_frame_stats* stats, uint32_t n_frames)
 {
     if (!h || !stats) return RPW_ERR_INVALID;
-    if (n_frames > h->last_frames) return fail(h, RPW_ERR_INVALID, "asked for %u frames, last batch had %u", n_frames, h->last_frames);
+    if (n_frames > h->ws.last_frames) return fail(h, RPW_ERR_INVALID, "asked for %u frames, last batch had %u", n_frames, h->ws.last_frames);
     RPW_HIP(h, hipSetDevice(h->device));
-    RPW_HIP(h, hipStreamSynchronize(h->last_stream));
-    if (n_frames) RPW_HIP(h, hipMemcpy(stats, h->d_stats, n_frames * sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
+    RPW_HIP(h, hipStreamSynchronize(h->ws.last_stream));
+    if (n_frames) RPW_HIP(h, hipMemcpy(stats, h->ws.d_stats, n_frames * sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
     return RPW_OK;
 }
 
@@ -428,12 +594,12 @@ rpw_status rpw_segment(rpw_handle* h, const float* xyz, uint32_t n, uint8_t* lab
     hipStream_t s = h->own_stream;
     if (n) RPW_HIP(h, hipMemcpyAsync(h->d_in, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
     const uint32_t off[2] = {0, n};
-    rpw_status st = run_batch(h, h->d_in, off, 1, h->d_labels, residual ? h->d_res : nullptr, s);
+    rpw_status st = run_batch(h, h->ws, h->d_in, off, 1, h->d_labels, residual ? h->d_res : nullptr, s);
     if (st != RPW_OK) return st;
     if (n) RPW_HIP(h, hipMemcpyAsync(labels, h->d_labels, n, hipMemcpyDeviceToHost, s));
     if (n && residual) RPW_HIP(h, hipMemcpyAsync(residual, h->d_res, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
     RPW_HIP(h, hipStreamSynchronize(s));
-    if (stats) RPW_HIP(h, hipMemcpy(stats, h->d_stats, sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
+    if (stats) RPW_HIP(h, hipMemcpy(stats, h->ws.d_stats, sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
     return RPW_OK;
 }
 
@@ -443,8 +609,7 @@ rpw_status rpw_segment_pointcloud2(rpw_handle* h, const uint8_t* data, uint32_t 
 {
     if (!h) return RPW_ERR_INVALID;
     if (n && (!data || !labels)) return fail(h, RPW_ERR_INVALID, "null pointer");
-    if (point_step < 12 || (point_step & 3u) || (off_x & 3u) || (off_y & 3u) || (off_z & 3u) ||
-        off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step)
+    if (!pc2_layout_ok(point_step, off_x, off_y, off_z))
         return fail(h, RPW_ERR_INVALID, "PointCloud2 layout: point_step %u, x/y/z offsets %u/%u/%u must be 4-byte aligned FLOAT32 fields inside the record",
                     point_step, off_x, off_y, off_z);
     if (n > h->max_points) return fail(h, RPW_ERR_CAPACITY, "frame of %u points > capacity %u", n, h->max_points);
@@ -463,12 +628,103 @@ rpw_status rpw_segment_pointcloud2(rpw_handle* h, const uint8_t* data, uint32_t 
     if (n) RPW_HIP(h, hipMemcpyAsync(h->d_raw, data, need, hipMemcpyHostToDevice, s));
     const uint32_t off[2] = {0, n};
     InputLayout lay; lay.stride = point_step; lay.off[0] = off_x; lay.off[1] = off_y; lay.off[2] = off_z;
-    rpw_status st = run_batch(h, h->d_raw, off, 1, h->d_labels, residual ? h->d_res : nullptr, s, lay);
+    rpw_status st = run_batch(h, h->ws, h->d_raw, off, 1, h->d_labels, residual ? h->d_res : nullptr, s, lay);
     if (st != RPW_OK) return st;
     if (n) RPW_HIP(h, hipMemcpyAsync(labels, h->d_labels, n, hipMemcpyDeviceToHost, s));
     if (n && residual) RPW_HIP(h, hipMemcpyAsync(residual, h->d_res, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
     RPW_HIP(h, hipStreamSynchronize(s));
-    if (stats) RPW_HIP(h, hipMemcpy(stats, h->d_stats, sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
+    if (stats) RPW_HIP(h, hipMemcpy(stats, h->ws.d_stats, sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
+    return RPW_OK;
+}
+
+/* ---- host-pointer pipeline: K frames in flight, one slot each ---------------------------------------------------- */
+
+rpw_status rpw_set_pipeline(rpw_handle* h, uint32_t n_slots)
+{
+    if (!h) return RPW_ERR_INVALID;
+    if (n_slots > RPW_MAX_SLOTS) return fail(h, RPW_ERR_UNSUPPORTED, "%u pipeline slots > %d", n_slots, RPW_MAX_SLOTS);
+    RPW_HIP(h, hipSetDevice(h->device));
+    while (h->slots.size() > n_slots) { free_slot(h->slots.back()); h->slots.pop_back(); }   // (waits for the slot's frame)
+    while (h->slots.size() < n_slots) {
+        Slot* s = new (std::nothrow) Slot();
+        if (!s) return fail(h, RPW_ERR_INVALID, "out of host memory");
+        h->slots.push_back(s);
+        rpw_status st = alloc_slot(h, s);
+        if (st != RPW_OK) { free_slot(s); h->slots.pop_back(); return st; }
+    }
+    return RPW_OK;
+}
+
+uint32_t rpw_get_pipeline(const rpw_handle* h) { return h ? (uint32_t)h->slots.size() : 0u; }
+
+float* rpw_slot_input(rpw_handle* h, uint32_t slot)
+{
+    Slot* s = h ? get_slot(h, slot) : nullptr;
+    return s ? reinterpret_cast<float*>(s->h_in) : nullptr;
+}
+
+rpw_status rpw_submit(rpw_handle* h, uint32_t slot, const float* xyz, uint32_t n, uint32_t flags)
+{
+    if (!h) return RPW_ERR_INVALID;
+    Slot* s = get_slot(h, slot);
+    if (!s) return fail(h, RPW_ERR_INVALID, "slot %u does not exist (rpw_set_pipeline made %zu)", slot, h->slots.size());
+    if (s->pending) return fail(h, RPW_ERR_BUSY, "slot %u still holds a frame: rpw_wait it first", slot);
+    if (n && !xyz) return fail(h, RPW_ERR_INVALID, "null pointer");
+    if (n > h->max_points) return fail(h, RPW_ERR_CAPACITY, "frame of %u points > capacity %u", n, h->max_points);
+    RPW_HIP(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)n * 3 * sizeof(float);
+    if (n && reinterpret_cast<const unsigned char*>(xyz) != s->h_in) std::memcpy(s->h_in, xyz, bytes);   // filled in place: nothing to copy
+    return enqueue_slot(h, s, n, bytes, InputLayout(), (flags & RPW_SUBMIT_RESIDUAL) != 0);
+}
+
+rpw_status rpw_submit_pointcloud2(rpw_handle* h, uint32_t slot, const uint8_t* data, uint32_t n, uint32_t point_step,
+                                  uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t flags)
+{
+    if (!h) return RPW_ERR_INVALID;
+    Slot* s = get_slot(h, slot);
+    if (!s) return fail(h, RPW_ERR_INVALID, "slot %u does not exist (rpw_set_pipeline made %zu)", slot, h->slots.size());
+    if (s->pending) return fail(h, RPW_ERR_BUSY, "slot %u still holds a frame: rpw_wait it first", slot);
+    if (n && !data) return fail(h, RPW_ERR_INVALID, "null pointer");
+    if (!pc2_layout_ok(point_step, off_x, off_y, off_z))
+        return fail(h, RPW_ERR_INVALID, "PointCloud2 layout: point_step %u, x/y/z offsets %u/%u/%u must be 4-byte aligned FLOAT32 fields inside the record",
+                    point_step, off_x, off_y, off_z);
+    if (n > h->max_points) return fail(h, RPW_ERR_CAPACITY, "frame of %u points > capacity %u", n, h->max_points);
+    RPW_HIP(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)n * point_step;
+    if (bytes > s->h_in_bytes) {                     // records wider than 12 bytes: the slot's staging grows on demand
+        (void)hipHostFree(s->h_in); s->h_in = nullptr; s->h_in_bytes = 0;
+        RPW_HIP(h, hipHostMalloc((void**)&s->h_in, bytes, hipHostMallocDefault)); s->h_in_bytes = bytes;
+    }
+    if (bytes && data != s->h_in) std::memcpy(s->h_in, data, bytes);
+    InputLayout lay; lay.stride = point_step; lay.off[0] = off_x; lay.off[1] = off_y; lay.off[2] = off_z;
+    return enqueue_slot(h, s, n, bytes, lay, (flags & RPW_SUBMIT_RESIDUAL) != 0);
+}
+
+rpw_status rpw_poll(rpw_handle* h, uint32_t slot, int* done)
+{
+    if (!h || !done) return RPW_ERR_INVALID;
+    Slot* s = get_slot(h, slot);
+    if (!s) return fail(h, RPW_ERR_INVALID, "slot %u does not exist", slot);
+    if (!s->pending) return fail(h, RPW_ERR_INVALID, "slot %u holds no frame", slot);
+    const hipError_t e = hipEventQuery(s->done);
+    if (e == hipSuccess) { *done = 1; return RPW_OK; }
+    if (e == hipErrorNotReady) { *done = 0; return RPW_OK; }
+    return fail(h, RPW_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+}
+
+rpw_status rpw_wait(rpw_handle* h, uint32_t slot, uint8_t* labels, float* residual, rpw_frame_stats* stats)
+{
+    if (!h) return RPW_ERR_INVALID;
+    Slot* s = get_slot(h, slot);
+    if (!s) return fail(h, RPW_ERR_INVALID, "slot %u does not exist", slot);
+    if (!s->pending) return fail(h, RPW_ERR_INVALID, "slot %u holds no frame: rpw_submit first", slot);
+    if (s->n && !labels) return fail(h, RPW_ERR_INVALID, "labels is null");
+    if (residual && !s->want_residual) return fail(h, RPW_ERR_INVALID, "slot %u was submitted without RPW_SUBMIT_RESIDUAL", slot);
+    RPW_HIP(h, hipEventSynchronize(s->done));
+    s->pending = false;                               // the frame is done, whatever the caller takes of it
+    if (s->n) std::memcpy(labels, s->h_labels, s->n);
+    if (s->n && residual) std::memcpy(residual, s->h_res, (size_t)s->n * sizeof(float));
+    if (stats) *stats = *s->h_stats;
     return RPW_OK;
 }
 
@@ -524,12 +780,12 @@ rpw_status rpw_segment_fused(rpw_handle* h, const float* xyz, const uint32_t* se
     hipStream_t s = h->own_stream;
     if (n) RPW_HIP(h, hipMemcpyAsync(h->d_in, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
     const uint32_t off[2] = {0, n};
-    rpw_status st = run_batch(h, h->d_in, off, 1, h->d_labels, residual ? h->d_res : nullptr, s, InputLayout(), sensor_offsets);
+    rpw_status st = run_batch(h, h->ws, h->d_in, off, 1, h->d_labels, residual ? h->d_res : nullptr, s, InputLayout(), sensor_offsets);
     if (st != RPW_OK) return st;
     if (n) RPW_HIP(h, hipMemcpyAsync(labels, h->d_labels, n, hipMemcpyDeviceToHost, s));
     if (n && residual) RPW_HIP(h, hipMemcpyAsync(residual, h->d_res, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
     RPW_HIP(h, hipStreamSynchronize(s));
-    if (stats) RPW_HIP(h, hipMemcpy(stats, h->d_stats, sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
+    if (stats) RPW_HIP(h, hipMemcpy(stats, h->ws.d_stats, sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
     return RPW_OK;
 }
 
@@ -540,7 +796,7 @@ rpw_status rpw_segment_batch_device_fused(rpw_handle* h, const float* d_xyz, con
     if (!h) return RPW_ERR_INVALID;
     if (h->sensors.n <= 0) return fail(h, RPW_ERR_INVALID, "rpw_set_sensors has not been called");
     if (!sensor_offsets) return fail(h, RPW_ERR_INVALID, "sensor_offsets is null");
-    return run_batch(h, d_xyz, frame_offsets, n_frames, d_labels, d_residual, (hipStream_t)stream, InputLayout(), sensor_offsets);
+    return run_batch(h, h->ws, d_xyz, frame_offsets, n_frames, d_labels, d_residual, (hipStream_t)stream, InputLayout(), sensor_offsets);
 }
 
 rpw_status rpw_set_trace(rpw_handle* h, int enable, uint32_t max_nodes)
@@ -560,9 +816,9 @@ rpw_status rpw_get_nodes(rpw_handle* h, rpw_node* nodes, uint32_t cap, uint32_t*
     *n_nodes = 0;
     if (!h->trace || !h->d_nodes) return fail(h, RPW_ERR_INVALID, "trace is not enabled");
     RPW_HIP(h, hipSetDevice(h->device));
-    RPW_HIP(h, hipStreamSynchronize(h->last_stream));
+    RPW_HIP(h, hipStreamSynchronize(h->ws.last_stream));
     uint32_t cnt = 0;
-    RPW_HIP(h, hipMemcpy(&cnt, h->d_ctrl + kBuckets, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    RPW_HIP(h, hipMemcpy(&cnt, h->ws.d_ctrl + kBuckets, sizeof(uint32_t), hipMemcpyDeviceToHost));
     *n_nodes = cnt;
 #if defined(RPW_STAMPS)
     cnt = h->nodes_cap;   /* diagnostic build: return the whole buffer (stamps sit in its tail) */

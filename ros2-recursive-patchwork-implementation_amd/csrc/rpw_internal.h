@@ -83,6 +83,9 @@ struct DevParams {
 void launch_bin(const DevParams& p, hipStream_t s);
 void launch_scan(const DevParams& p, hipStream_t s);
 void launch_fit(const DevParams& p, hipStream_t s);
+void launch_frame_setup(uint32_t* offsets, uint32_t n, uint32_t tiles, uint32_t* ctrl, uint32_t ctrl_words, hipStream_t s);
+void launch_frame_copy_out(const uint8_t* labels, uint8_t* h_labels, uint32_t n, const float* res, float* h_res,
+                           const rpw_frame_stats* stats, rpw_frame_stats* h_stats, hipStream_t s);
 void launch_debug_angles(const float* x, const float* y, float* a, uint32_t n, hipStream_t s);
 void launch_debug_eig3(const float* cov9, float* normal3, uint32_t n, hipStream_t s);
 

@@ -16,6 +16,7 @@
 // by one lane per accumulator (the consumer wave); the producer wave only prepares the
 // addends. Built with -ffp-contract=off; divide and sqrt are correctly rounded.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "rpw_internal.h"
 
 namespace rpw {
@@ -1156,6 +1157,754 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
     }
 }
 
+// ==========================================================================================
+// K3, single-wave form: ONE WAVE per (frame, patch), nothing shared with any other wave.
+//
+// The two-wave kernel above is bound by its producer: turning 64 points into compacted addends costs it ~170
+// instructions per ring slot (a lone wave issues one every 4 cycles: 680 cycles), while the chain needs
+// 64 x 8.2 = 525, and every slot costs a rendezvous on top. Here the work is cut differently:
+//   * a MASK PASS (data-parallel, no chain) evaluates the inlier predicate of every slot of the node, keeps the
+//     mask history byte and writes the slot numbers of the inliers, in slot order, into an index list;
+//   * a CHAIN SWEEP walks that list 64 inliers at a time: gather x, y, z, make the K addends, transpose them
+//     through a two-slot LDS ring, and run the K sequential sums (accumulator k in lane k) -- all in ONE
+//     instruction stream. A dependent v_add_f32 issues every ~8 cycles and a lone wave issues every 4, so the
+//     ~50 instructions that feed the next slot ride in the chain's shadow: the chain runs at its own speed and
+//     no barrier, flag or second wave is involved.
+// Per refit iteration: covariance sweep over the inliers (6 rows) -> eigenvector -> mask pass over the node ->
+// centroid sweep over the new inliers (3 rows), or, when the mask did not change, the residual sweep (1 row).
+// Everything else (gather, early-outs, order statistics, partition, labels) is the same arithmetic as above,
+// executed by 64 lanes. Sums are accumulated in exactly the reference's order (recursive_patchwork.cpp:98-104,
+// 383-387, 241-248; point_cloud_processor.cpp:63-67, 78-83).
+// ==========================================================================================
+constexpr int kW1Ring = 2;
+
+struct Fit1Shared {
+    union {                            // the gather prologue is over before the first chain sweep
+        __attribute__((aligned(16))) float ring[kW1Ring * kSlotFloats];
+        struct {
+            uint32_t toff[kGatherTiles];
+            uint32_t tsrc[kGatherTiles];
+        } dir;
+    };
+    uint32_t hist[256];
+    uint32_t stk[3 * kStackDepth];
+};
+
+struct W1 {
+    const float *sx, *sy, *sz;         // patch-sorted SoA
+    uint32_t* il;                      // inlier index list of the current node (node-relative slot numbers, ascending)
+    uint8_t* mask;
+    Fit1Shared* sh;
+    uint32_t base;                     // absolute slot of the patch's first point
+    int lane;
+    unsigned long long addends;        // chain steps so far (statistics)
+};
+
+struct P4 { float x, y, z; uint32_t m; };
+
+typedef __attribute__((address_space(3))) float lds_f32;
+
+// The node a pass works on, as plain pointers to its first slot (by value: the passes are real functions, not inlined
+// copies -- six inlined sweeps made the compiler hoist six sets of loop invariants over the whole node loop, 253 VGPRs).
+// (explicit global address space: a plain pointer that arrives as a function argument is "generic", and generic
+// accesses compile to flat_ instructions that count against the LDS counter as well)
+typedef __attribute__((address_space(1))) const float g_cf32;
+typedef __attribute__((address_space(1))) uint8_t g_u8;
+typedef __attribute__((address_space(1))) uint32_t g_u32;
+struct NodeRef {
+    g_cf32 *x, *y, *z;                 // patch-sorted SoA, at the node's first slot
+    g_u8* m;                           // mask history bytes
+    g_u32* il;                         // inlier index list (node-relative slot numbers, ascending)
+    uint32_t n;                        // slots in the node
+};
+__device__ __forceinline__ float ldg_f32(g_cf32* base, uint32_t slot)
+{
+    return *reinterpret_cast<g_cf32*>(reinterpret_cast<__attribute__((address_space(1))) const char*>(base) + slot * 4u);
+}
+
+// slot min(i, n-1) of the node, raw: lanes past the end read the last slot again (never used)
+__device__ __forceinline__ P4 w1_load(const NodeRef& nd, int lane, uint32_t chunk)
+{
+    P4 r;
+    const uint32_t i = chunk * kWave + lane;
+    const uint32_t g = i < nd.n ? i : nd.n - 1u;
+    r.x = ldg_f32(nd.x, g); r.y = ldg_f32(nd.y, g); r.z = ldg_f32(nd.z, g);
+    r.m = (uint32_t)nd.m[g];
+    return r;
+}
+
+// MASK PASS over the node: evaluates the inlier predicate of every slot, keeps the mask history byte, and writes the
+// inliers' slot numbers to the index list in slot order.
+//   kMaskSeed   inlier = z < prm.thr                      byte := inlier
+//   kMaskPlane  inlier = |(p - c) . n| < prm.thr          byte := inlier | history << 1; flags: changed / differs from the mask before
+//   kMaskOlder  inlier = bit 1 of the byte (the mask one iteration back); the byte is left alone
+enum { kMaskSeed = 0, kMaskPlane = 1, kMaskOlder = 2 };
+struct MaskPrm { float cx, cy, cz, nx, ny, nz, thr; };
+struct MaskOut { uint32_t count, changed, differs_prev; };
+
+__device__ __attribute__((noinline)) MaskOut w1_mask_pass(NodeRef nd, int mode, MaskPrm prm)
+{
+    const int lane = threadIdx.x;
+    uint32_t cursor = 0;
+    const uint32_t n = nd.n;
+    const uint32_t nch = (n + kWave - 1) / kWave;
+    typedef __attribute__((address_space(1))) char g_char;
+    g_char* il = reinterpret_cast<g_char*>(nd.il);
+    bool changed = false, differs_prev = false;
+    P4 r0 = w1_load(nd, lane, 0), r1 = w1_load(nd, lane, 1), r2 = w1_load(nd, lane, 2), r3 = w1_load(nd, lane, 3);
+    for (uint32_t c = 0; c < nch; c += 4) {                       // four register sets, each reloaded right after use
+#define RPW_W1_MASK_STEP(R, CC)                                                                             \
+        if ((CC) < nch) {                                                                                   \
+            const uint32_t i = (CC) * kWave + lane;                                                         \
+            const bool ok = i < n;                                                                          \
+            bool in;                                                                                        \
+            if (mode == kMaskPlane) {                                                                       \
+                const float d = plane_dist(R.x, R.y, R.z, prm.cx, prm.cy, prm.cz, prm.nx, prm.ny, prm.nz); \
+                in = d < prm.thr;                                                                           \
+                const bool old = R.m & 1u, prev = (R.m >> 1) & 1u;                                         \
+                changed |= ok && (in != old);                                                               \
+                differs_prev |= ok && (in != prev);                                                         \
+                if (ok) nd.m[i] = (uint8_t)((in ? 1u : 0u) | ((R.m & 0x7fu) << 1));                       \
+            } else if (mode == kMaskSeed) {                                                                 \
+                in = R.z < prm.thr;                                                                         \
+                if (ok) nd.m[i] = in ? 1 : 0;                                                               \
+            } else {                                                                                        \
+                in = (R.m >> 1) & 1u;                                                                       \
+            }                                                                                               \
+            in = in && ok;                                                                                  \
+            const unsigned long long m = ballot64(in);                                                      \
+            if (in) *reinterpret_cast<g_u32*>(il + (cursor + (uint32_t)mbcnt64(m)) * 4u) = i;              \
+            cursor += (uint32_t)__popcll(m);                                                                \
+            R = w1_load(nd, lane, (CC) + 4);                                                                \
+        }
+        RPW_W1_MASK_STEP(r0, c) RPW_W1_MASK_STEP(r1, c + 1) RPW_W1_MASK_STEP(r2, c + 2) RPW_W1_MASK_STEP(r3, c + 3)
+#undef RPW_W1_MASK_STEP
+    }
+    MaskOut o;
+    o.count = cursor;
+    o.changed = ballot64(changed) != 0ull ? 1u : 0u;
+    o.differs_prev = ballot64(differs_prev) != 0ull ? 1u : 0u;
+    return o;
+}
+
+struct X3 { float x, y, z; };
+
+// CHAIN SWEEP: K sequential sums over `count` elements of the node, element j being slot il[j] (indexed) or slot j
+// (every slot of the node). sums[k] = ((a_0 + a_1) + ...) in element order, starting from +0, exactly as a scalar loop
+// accumulates them; accumulator k lives in lane k. What an element's addends are:
+//   kSweepXYZ     x, y, z                                   centroid sums (point_cloud_processor.cpp:63-67)
+//   kSweepCov     products of (p - c), lower triangle       covariance sums (point_cloud_processor.cpp:78-83); prm = c
+//   kSweepDist    |(p - c) . n|                             residual sum (recursive_patchwork.cpp:98-104); prm = c, n
+//   kSweepRange   sqrtf(x*x + y*y)                          mean distance (recursive_patchwork.cpp:383-387)
+//   kSweepXY      x, y                                      centroid for the split variance (recursive_patchwork.cpp:239)
+//   kSweepVarXY   (x - mx)^2, (y - my)^2                    split variances (recursive_patchwork.cpp:241-248); prm = mx, my
+// The loop is ONE instruction stream: the 64 dependent adds of slot t (one per ~8 cycles) with the loads, arithmetic
+// and LDS transposition of slot t + 1 issued in between.
+enum { kSweepXYZ = 0, kSweepCov = 1, kSweepDist = 2, kSweepRange = 3, kSweepXY = 4, kSweepVarXY = 5 };
+struct SweepPrm { float a, b, c, d, e, f; };
+struct Sums6 { float v[6]; };
+
+template <int MODE> struct SweepRows { static constexpr int K = MODE == kSweepCov ? 6 : (MODE == kSweepXYZ ? 3 : ((MODE == kSweepXY || MODE == kSweepVarXY) ? 2 : 1)); };
+
+// One slot = 64 elements = 16 steps of {one ds_read_b128 of the row, four dependent adds}. A step's adds take ~33 cycles
+// of latency but only five issue slots, so every step carries a few instructions of the NEXT slots' preparation; the
+// scheduling barriers pin them there (left alone, the compiler gathers the LDS reads right in front of their use).
+//   steps 0-7  (first half of slot t, second half's reads)   : addends of slot t + 1 -> ring
+//   steps 8-15 (second half of slot t, reads of slot t + 1)   : point loads of slot t + 4, index load of slot t + 6
+template <int MODE, bool INDEXED>
+__device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count, const SweepPrm& prm, lds_f32* ring, int lane)
+{
+    constexpr int K = SweepRows<MODE>::K;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4f lds_f4;
+    const uint32_t nslots = (count + kWave - 1) / kWave;
+    typedef __attribute__((address_space(1))) const char g_cchar;
+    g_cchar* il = reinterpret_cast<g_cchar*>(nd.il);
+    const uint32_t last = count - 1u;
+    // element j of slot u -> node slot (clamped: lanes past the end repeat the last element; their addends are replaced)
+    auto index_of = [&](uint32_t u) -> uint32_t {
+        const uint32_t j = u * kWave + lane, jc = j < last ? j : last;
+        return INDEXED ? *reinterpret_cast<const g_u32*>(il + jc * 4u) : jc;
+    };
+    auto point_of = [&](uint32_t idx) -> X3 {
+        X3 q; q.x = ldg_f32(nd.x, idx); q.y = ldg_f32(nd.y, idx);
+        q.z = (MODE == kSweepXYZ || MODE == kSweepCov || MODE == kSweepDist) ? ldg_f32(nd.z, idx) : 0.0f;
+        return q;
+    };
+    // addends of one element, in two halves (so that they can sit in two different steps)
+    float v[6];
+    f2 dxy; float dz;
+    auto make_a = [&](const X3& q) __attribute__((always_inline)) {
+        if (MODE == kSweepCov) {
+            // two-wide float arithmetic (v_pk_add_f32 / v_pk_mul_f32: each half is an ordinary IEEE binary32 operation)
+            dxy = f2{q.x, q.y} - f2{prm.a, prm.b};
+            dz = q.z - prm.c;
+            const f2 a = dxy * f2{dxy.x, dxy.x};            // dx*dx, dy*dx
+            v[0] = a.x; v[1] = a.y;                         // (0,0) (1,0)
+        } else if (MODE == kSweepXYZ) { v[0] = q.x; v[1] = q.y; v[2] = q.z; }
+        else if (MODE == kSweepDist)  { v[0] = plane_dist(q.x, q.y, q.z, prm.a, prm.b, prm.c, prm.d, prm.e, prm.f); }
+        else if (MODE == kSweepRange) { v[0] = sqrt_rn(q.x * q.x + q.y * q.y); }
+        else if (MODE == kSweepXY)    { v[0] = q.x; v[1] = q.y; }
+        else { const float dx = q.x - prm.a, dy = q.y - prm.b; v[0] = dx * dx; v[1] = dy * dy; }
+    };
+    auto make_b = [&]() __attribute__((always_inline)) {
+        if (MODE == kSweepCov) {
+            const f2 b = f2{dxy.y, dz} * f2{dxy.y, dxy.x};  // dy*dy, dz*dx
+            const f2 c = f2{dz, dz} * f2{dxy.y, dz};        // dz*dy, dz*dz
+            v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; // (1,1) (2,0) (2,1) (2,2)
+        }
+    };
+    // rows [k0, k1) of slot u into ring slot u & 1 (row k at k * kLdw, column = lane); columns past the end get -0.0f,
+    // the exact additive identity (a select, not a branch: the loop body must stay ONE basic block, or the adds
+    // are sunk out of their steps)
+    auto put = [&](uint32_t u, int k0, int k1) __attribute__((always_inline)) {
+        lds_f32* dst = ring + (u & (kW1Ring - 1)) * kSlotFloats + lane;
+        const bool live = u * kWave + lane < count;
+#pragma unroll
+        for (int k = k0; k < k1 && k < K; ++k) dst[k * kLdw] = live ? v[k] : -0.0f;
+    };
+    // Pipeline: the index list runs two slots ahead of the point loads, the points three slots ahead of their addends.
+    // Three register sets each, used round robin and reloaded right after use (the loop is unrolled by three): nothing
+    // is ever copied, so no instruction touches a value that has just been requested from memory.
+    //   P[u % 3] holds the points of slot u; I[u % 3] the indices of slot u.
+    uint32_t I1 = index_of(4), I2 = index_of(5), I0 = 0;
+    X3 P1 = point_of(index_of(1)), P2 = point_of(index_of(2)), P0 = point_of(index_of(3));
+    {
+        const X3 p0 = point_of(index_of(0));
+        make_a(p0); make_b(); put(0, 0, 6);
+    }
+    const int row = lane < K ? lane : K - 1;
+    const lds_f32* rowp = ring + row * kLdw;
+    float acc = 0.0f;
+    v4f A[8], B[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const lds_f4*>(rowp + 4 * q);
+#define RPW_W1_STEP_B(Q, FILL) { B[Q] = *reinterpret_cast<const lds_f4*>(cur + 4 * (Q)); RPW_CHAIN4(acc, A[Q]) FILL; __builtin_amdgcn_sched_barrier(0); }
+#define RPW_W1_STEP_A(Q, FILL) { A[Q] = *reinterpret_cast<const lds_f4*>(nxt + 4 * (Q)); RPW_CHAIN4(acc, B[Q]) FILL; __builtin_amdgcn_sched_barrier(0); }
+    // slot T: P_CUR holds slot T + 1 and is reloaded with slot T + 4 (indices I_USE); I_LOAD receives the indices of slot T + 6
+#define RPW_W1_SLOT(T, P_CUR, I_USE, I_LOAD) {                                                              \
+        const lds_f32* cur = rowp + ((T) & (kW1Ring - 1)) * kSlotFloats + 32;                               \
+        const lds_f32* nxt = rowp + (((T) + 1) & (kW1Ring - 1)) * kSlotFloats;                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        RPW_W1_STEP_B(0, make_a(P_CUR))                                                                     \
+        RPW_W1_STEP_B(1, make_b())                                                                          \
+        RPW_W1_STEP_B(2, put((T) + 1, 0, 2))                                                                \
+        RPW_W1_STEP_B(3, put((T) + 1, 2, 4))                                                                \
+        RPW_W1_STEP_B(4, put((T) + 1, 4, 6))                                                                \
+        RPW_W1_STEP_B(5, (void)0)                                                                           \
+        RPW_W1_STEP_B(6, (void)0)                                                                           \
+        RPW_W1_STEP_B(7, (void)0)                                                                           \
+        RPW_W1_STEP_A(0, (P_CUR = point_of(I_USE)))                                                         \
+        RPW_W1_STEP_A(1, (I_LOAD = index_of((T) + 6)))                                                      \
+        RPW_W1_STEP_A(2, (void)0)                                                                           \
+        RPW_W1_STEP_A(3, (void)0)                                                                           \
+        RPW_W1_STEP_A(4, (void)0)                                                                           \
+        RPW_W1_STEP_A(5, (void)0)                                                                           \
+        RPW_W1_STEP_A(6, (void)0)                                                                           \
+        RPW_W1_STEP_A(7, (void)0)                                                                           \
+    }
+    for (uint32_t t = 0; t < nslots; t += 3) {
+        RPW_W1_SLOT(t, P1, I1, I0)
+        if (t + 1 >= nslots) break;
+        RPW_W1_SLOT(t + 1, P2, I2, I1)
+        if (t + 2 >= nslots) break;
+        RPW_W1_SLOT(t + 2, P0, I0, I2)
+    }
+#undef RPW_W1_SLOT
+#undef RPW_W1_STEP_A
+#undef RPW_W1_STEP_B
+    return acc;
+}
+
+__device__ __attribute__((noinline)) Sums6 w1_chain_sweep(NodeRef nd, uint32_t count, int mode, int indexed, SweepPrm prm, lds_f32* ring)
+{
+    const int lane = threadIdx.x;
+    Sums6 out;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out.v[k] = 0.0f;
+    if (count == 0) return out;
+    float acc;
+    // (mode and indexed arrive in vector registers; the wave-uniform copy makes these scalar branches)
+    switch (__builtin_amdgcn_readfirstlane(mode)) {
+    case kSweepCov:   acc = w1_sweep_loop<kSweepCov, true>(nd, count, prm, ring, lane); break;
+    case kSweepXYZ:   acc = w1_sweep_loop<kSweepXYZ, true>(nd, count, prm, ring, lane); break;
+    case kSweepDist:  acc = w1_sweep_loop<kSweepDist, true>(nd, count, prm, ring, lane); break;
+    case kSweepRange: acc = w1_sweep_loop<kSweepRange, false>(nd, count, prm, ring, lane); break;
+    case kSweepXY:    acc = w1_sweep_loop<kSweepXY, false>(nd, count, prm, ring, lane); break;
+    default:          acc = w1_sweep_loop<kSweepVarXY, false>(nd, count, prm, ring, lane); break;
+    }
+    (void)indexed;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out.v[k] = __shfl(acc, k);
+    return out;
+}
+
+// exact order statistic, single wave (see select_rank)
+__device__ __attribute__((noinline)) float w1_select_rank(W1 cx, uint32_t s, uint32_t n, int axis, uint32_t k)
+{
+    const float* src = (axis == 0 ? cx.sx : (axis == 1 ? cx.sy : cx.sz)) + cx.base + s;
+    uint32_t* hist = cx.sh->hist;
+    uint32_t prefix = 0, pmask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int j = cx.lane; j < 256; j += kWave) hist[j] = 0;
+        __syncthreads();
+        for (uint32_t i = cx.lane; i < n; i += kWave) {
+            const uint32_t key = float_key(src[i]);
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        const uint32_t h0 = hist[4 * cx.lane], h1 = hist[4 * cx.lane + 1], h2 = hist[4 * cx.lane + 2], h3 = hist[4 * cx.lane + 3];
+        const uint32_t tot = h0 + h1 + h2 + h3;
+        const uint32_t incl = wave_incl_scan(tot);
+        const uint32_t excl = incl - tot;
+        const bool mine = (k >= excl) && (k < incl);
+        const unsigned long long bm = ballot64(mine);
+        const int owner = __ffsll((long long)bm) - 1;
+        uint32_t bin = 0, before = 0;
+        if (mine) {
+            uint32_t c = excl;
+            if (k < c + h0) { bin = 4 * cx.lane; before = c; }
+            else { c += h0; if (k < c + h1) { bin = 4 * cx.lane + 1; before = c; }
+            else { c += h1; if (k < c + h2) { bin = 4 * cx.lane + 2; before = c; }
+            else { c += h2; bin = 4 * cx.lane + 3; before = c; } } }
+        }
+        bin = __shfl(bin, owner); before = __shfl(before, owner);
+        prefix |= bin << shift; pmask |= 255u << shift;
+        k -= before;
+        __syncthreads();
+    }
+    return key_float(prefix);
+}
+
+// libstdc++ partial_sort(3 lowest z) restated, single wave (see three_lowest)
+struct Sel3 { uint32_t v[3]; };
+__device__ __attribute__((noinline)) Sel3 w1_three_lowest(W1 cx, uint32_t s, uint32_t n)
+{
+    const float* zs = cx.sz + cx.base + s;
+    uint32_t h0 = 0, h1 = 1, h2 = 2;
+    float z0 = zs[0], z1 = zs[1], z2 = zs[2];
+    auto adjust = [&](uint32_t vi, float vz) {
+        int hole;
+        if (z2 < z1) { h0 = h1; z0 = z1; hole = 1; } else { h0 = h2; z0 = z2; hole = 2; }
+        if (z0 < vz) { if (hole == 1) { h1 = h0; z1 = z0; } else { h2 = h0; z2 = z0; } h0 = vi; z0 = vz; }
+        else { if (hole == 1) { h1 = vi; z1 = vz; } else { h2 = vi; z2 = vz; } }
+    };
+    adjust(h0, z0);
+    for (uint32_t b = 3; b < n; b += kWave) {
+        const uint32_t i = b + cx.lane;
+        const float zi = i < n ? zs[i] : 0.0f;
+        unsigned long long done = 0ull;
+        for (;;) {
+            const bool want = i < n && zi < z0 && !((done >> cx.lane) & 1ull);
+            const unsigned long long cand = ballot64(want);
+            if (!cand) break;
+            const int l = __ffsll((long long)cand) - 1;
+            const uint32_t vi = (uint32_t)__shfl((int)i, l);
+            const float vz = __shfl(zi, l);
+            adjust(vi, vz);
+            done |= (l == 63) ? ~0ull : ((1ull << (l + 1)) - 1ull);
+        }
+    }
+    Sel3 sel; sel.v[0] = h0; sel.v[1] = h1; sel.v[2] = h2;
+    return sel;
+}
+
+constexpr int kFit1Threads = kWave;
+
+struct N3 { float x, y, z; };
+// the Eigen 3.4.0 solver (rpw_math.h) as a real function: it is called once per refit, inlining it twice only costs registers
+__device__ __attribute__((noinline)) N3 w1_normal(float a00, float a10, float a11, float a20, float a21, float a22)
+{
+    N3 r;
+    smallest_eigenvector(a00, a10, a11, a20, a21, a22, r.x, r.y, r.z);
+    return r;
+}
+
+// Gather prologue (see patch_fit_kernel): assembles the patch's contiguous slots from its runs in the tile-sorted
+// records and returns the bounding box of the whole patch.
+struct Box6 { float v[6]; };
+typedef __attribute__((address_space(3))) uint32_t lds_word;
+struct GatherArgs {
+    const uint32_t *goff, *gdir;       // this patch's column of the run-length / run-start directories, first tile of the frame
+    const float4* tp;
+    float *sx, *sy, *sz; uint32_t* sidx;
+    uint32_t nt, PB, fo, begin, n;
+};
+__device__ __attribute__((noinline)) Box6 w1_gather(GatherArgs g, lds_word* toff, lds_word* tsrc)
+{
+    const int lane = threadIdx.x;
+    const uint32_t nt = g.nt;
+    const bool in_lds = nt <= (uint32_t)kGatherTiles;
+    if (in_lds) {
+        const uint32_t per = (nt + kFit1Threads - 1) / kFit1Threads;
+        const uint32_t ta = (uint32_t)lane * per, tb = ta + per < nt ? ta + per : nt;
+        uint32_t sum = 0;
+        for (uint32_t t = ta; t < tb; ++t) {
+            const uint32_t len = g.goff[(size_t)t * g.PB];
+            toff[t] = len; sum += len;
+            tsrc[t] = t * kTilePoints + g.gdir[(size_t)t * g.PB];
+        }
+        const uint32_t incl = wave_incl_scan(sum);
+        uint32_t run = incl - sum;
+        for (uint32_t t = ta; t < tb; ++t) { const uint32_t len = toff[t]; toff[t] = run; run += len; }
+    }
+    __syncthreads();
+    const uint32_t rel0 = in_lds ? 0u : g.begin - g.fo;
+    uint32_t top = 1; while (top * 2u < nt) top *= 2u;
+    constexpr int kGatherWide = 8;
+    float xmn = 3.402823466e+38f, xmx = -3.402823466e+38f, ymn = xmn, ymx = xmx, zmn = xmn, zmx = xmx;
+    for (uint32_t j0 = lane; j0 < g.n; j0 += kGatherWide * kFit1Threads) {
+        uint32_t src[kGatherWide], d[kGatherWide], lo[kGatherWide]; float4 v4[kGatherWide];
+#pragma unroll
+        for (int u = 0; u < kGatherWide; ++u) { const uint32_t j = j0 + u * kFit1Threads; d[u] = rel0 + (j < g.n ? j : g.n - 1u); lo[u] = 0; }
+        if (in_lds) {
+            for (uint32_t step = top; step > 0; step >>= 1) {
+                uint32_t v[kGatherWide];
+#pragma unroll
+                for (int u = 0; u < kGatherWide; ++u) { const uint32_t mid = lo[u] + step; v[u] = toff[mid < nt ? mid : nt - 1u]; }
+#pragma unroll
+                for (int u = 0; u < kGatherWide; ++u) { const uint32_t mid = lo[u] + step; lo[u] = ((mid < nt) & (v[u] <= d[u])) ? mid : lo[u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < kGatherWide; ++u) { const uint32_t o = toff[lo[u]], sb = tsrc[lo[u]]; src[u] = g.fo + sb + (d[u] - o); }
+        } else {
+            for (uint32_t step = top; step > 0; step >>= 1) {
+#pragma unroll
+                for (int u = 0; u < kGatherWide; ++u) {
+                    const uint32_t mid = lo[u] + step, mc = mid < nt ? mid : nt - 1u;
+                    lo[u] = (mid < nt && g.goff[(size_t)mc * g.PB] <= d[u]) ? mid : lo[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kGatherWide; ++u)
+                src[u] = g.fo + lo[u] * kTilePoints + g.gdir[(size_t)lo[u] * g.PB] + (d[u] - g.goff[(size_t)lo[u] * g.PB]);
+        }
+#pragma unroll
+        for (int u = 0; u < kGatherWide; ++u) v4[u] = g.tp[src[u]];
+#pragma unroll
+        for (int u = 0; u < kGatherWide; ++u) {
+            const uint32_t j = j0 + u * kFit1Threads;
+            if (j < g.n) {
+                const uint32_t dst = g.begin + j;
+                g.sx[dst] = v4[u].x; g.sy[dst] = v4[u].y; g.sz[dst] = v4[u].z; g.sidx[dst] = __float_as_uint(v4[u].w);
+            }
+            xmn = fminf(xmn, v4[u].x); xmx = fmaxf(xmx, v4[u].x); ymn = fminf(ymn, v4[u].y); ymx = fmaxf(ymx, v4[u].y);
+            zmn = fminf(zmn, v4[u].z); zmx = fmaxf(zmx, v4[u].z);
+        }
+    }
+    Box6 b;
+    b.v[0] = wave_min(xmn); b.v[1] = wave_max(xmx); b.v[2] = wave_min(ymn); b.v[3] = wave_max(ymx);
+    b.v[4] = wave_min(zmn); b.v[5] = wave_max(zmx);
+    return b;
+}
+
+__global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p)
+{
+    __shared__ Fit1Shared sh;
+    const int lane = threadIdx.x;
+
+    // ---- block -> patch, largest size bucket first --------------------------------------------
+    uint32_t linear;
+    {
+        const uint32_t cnt = p.bucket_count[kBuckets - 1 - lane];
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint32_t total = __shfl(incl, 63);
+        if (blockIdx.x >= total) return;
+        const unsigned long long bm = ballot64(blockIdx.x < incl);
+        const int l = __ffsll((long long)bm) - 1;
+        const uint32_t before = __shfl(incl - cnt, l);
+        linear = p.bucket_list[(size_t)(kBuckets - 1 - l) * p.list_stride + (blockIdx.x - before)];
+    }
+    const int frame = (int)(linear / (uint32_t)p.P), patch = (int)(linear % (uint32_t)p.P);
+    const PatchDesc pd = p.patches[linear];
+    const uint32_t fo = p.frame_off[frame];
+
+    W1 cx; cx.sx = p.sx; cx.sy = p.sy; cx.sz = p.sz; cx.il = reinterpret_cast<uint32_t*>(p.ax); cx.mask = p.mask; cx.sh = &sh;
+    cx.base = pd.begin; cx.lane = lane; cx.addends = 0ull;
+    const rpw_config& cfg = p.cfg;
+    uint32_t* stk = sh.stk;
+    float rootbox[6];
+
+    // ---- gather: assemble the patch's contiguous slots from its runs in the tile-sorted arrays ----------------
+    {
+        const uint32_t t0 = p.tile_base[frame];
+        GatherArgs g;
+        g.goff = p.hist + (size_t)t0 * p.PB + patch; g.gdir = p.tdir + (size_t)t0 * p.PB + patch; g.tp = p.tp;
+        g.sx = p.sx; g.sy = p.sy; g.sz = p.sz; g.sidx = p.sidx;
+        g.nt = p.tile_base[frame + 1] - t0; g.PB = (uint32_t)p.PB; g.fo = fo; g.begin = pd.begin; g.n = pd.n;
+        const Box6 b = w1_gather(g, (lds_word*)sh.dir.toff, (lds_word*)sh.dir.tsrc);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rootbox[k] = b.v[k];
+        __syncthreads();                               // the directory's LDS becomes the ring; the wave's own stores are ordered
+    }
+
+    // zone < 3: the reference returns {{}, cleaned} before looking at any patch (recursive_patchwork.cpp:339-341)
+    if (p.stats[frame].n_zone < 3u) {
+        for (uint32_t i = lane; i < pd.n; i += kFit1Threads) p.labels[fo + p.sidx[pd.begin + i]] = RPW_LABEL_NONGROUND;
+        return;
+    }
+
+    lds_f32* ring = (lds_f32*)sh.ring;            // address-space cast: the passes take the ring as an LDS pointer (ds_ instructions, not flat)
+    const SweepPrm no_prm = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    // ---- mean distance of the patch (recursive_patchwork.cpp:383-387): sequential sum of d ------
+    float mean_dist;
+    {
+        NodeRef root; root.x = (g_cf32*)(p.sx + cx.base); root.y = (g_cf32*)(p.sy + cx.base); root.z = (g_cf32*)(p.sz + cx.base);
+        root.m = (g_u8*)(p.mask + cx.base); root.il = (g_u32*)(cx.il + cx.base); root.n = pd.n;
+        const Sums6 sum = w1_chain_sweep(root, pd.n, kSweepRange, 0, no_prm, ring);
+        cx.addends += pd.n;
+        mean_dist = sum.v[0] / (float)pd.n;
+    }
+    const float rel_dist = mean_dist / cfg.filtering_radius;
+    const float threshold = cfg.th_dist * (1.0f + 0.2f * rel_dist);
+
+    PatchAcc pa; pa.nodes = 0; pa.splits = 0; pa.maxdepth = 0; pa.ground = 0; pa.iters = 0;
+    bool permuted = false;
+
+    int sp = 0;
+    if (lane == 0) { stk[0] = 0; stk[1] = pd.n; stk[2] = 0; }
+    sp = 1;
+    __syncthreads();
+
+    while (sp > 0) {
+        --sp;
+        const uint32_t s = stk[3 * sp], n = stk[3 * sp + 1];
+        const int depth = (int)stk[3 * sp + 2];
+        __syncthreads();
+        pa.nodes++;
+        if ((uint32_t)depth > pa.maxdepth) pa.maxdepth = (uint32_t)depth;
+        const float* gx = p.sx + cx.base + s;
+        const float* gy = p.sy + cx.base + s;
+        const float* gz = p.sz + cx.base + s;
+        uint8_t* gm = p.mask + cx.base + s;
+        const uint32_t* gi = p.sidx + cx.base + s;
+        uint32_t* gl = cx.il + cx.base + s;
+
+        // ---- early outs (recursive_patchwork.cpp:111-140) ---------------------------------------
+        int leaf_kind = -1;
+        if (n < 3 || depth > cfg.max_split_depth) leaf_kind = RPW_NODE_REJECT;
+        if (leaf_kind < 0) {
+            float xmn = rootbox[0], xmx = rootbox[1], ymn = rootbox[2], ymx = rootbox[3], zmn = rootbox[4], zmx = rootbox[5];
+            if (depth > 0) {
+                xmn = 3.402823466e+38f; xmx = -3.402823466e+38f; ymn = xmn; ymx = xmx; zmn = xmn; zmx = xmx;
+                for (uint32_t i0 = lane; i0 < n; i0 += 4 * kFit1Threads) {
+                    float x[4], y[4], z[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * kFit1Threads, ic = i < n ? i : n - 1u; x[u] = gx[ic]; y[u] = gy[ic]; z[u] = gz[ic]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        xmn = fminf(xmn, x[u]); xmx = fmaxf(xmx, x[u]); ymn = fminf(ymn, y[u]); ymx = fmaxf(ymx, y[u]);
+                        zmn = fminf(zmn, z[u]); zmx = fmaxf(zmx, z[u]);
+                    }
+                }
+                xmn = wave_min(xmn); xmx = wave_max(xmx); ymn = wave_min(ymn); ymx = wave_max(ymx);
+                zmn = wave_min(zmn); zmx = wave_max(zmx);
+            }
+            const float area = (xmx - xmn) * (ymx - ymn);
+            if (area < 25.0f && depth > 0) leaf_kind = RPW_NODE_SMALL;
+            else if ((zmx - zmn) < 0.05f && n > 10) leaf_kind = RPW_NODE_FLAT;
+        }
+        if (leaf_kind >= 0) {
+            const uint8_t lab = leaf_kind == RPW_NODE_REJECT ? RPW_LABEL_NONGROUND : RPW_LABEL_GROUND;
+            for (uint32_t i = lane; i < n; i += kFit1Threads) p.labels[fo + gi[i]] = lab;
+            if (leaf_kind != RPW_NODE_REJECT) pa.ground += n;
+            emit_node(p, lane, frame, patch, depth, s, n, leaf_kind, 0, leaf_kind == RPW_NODE_REJECT ? 0u : n, -1, 0.0f, nullptr);
+            continue;
+        }
+
+        // ---- seeds (recursive_patchwork.cpp:149-182) ---------------------------------------------
+        float z_th;
+        if (cfg.adaptive_seed_height) {
+            z_th = cfg.sensor_height + 0.2f * rel_dist;
+        } else {
+            const uint32_t idx = (uint32_t)(0.1f * (float)n);     // static_cast<size_t>(0.1f * size)
+            z_th = w1_select_rank(cx, s, n, 2, idx < n ? idx : n - 1) + cfg.th_seeds;
+        }
+        NodeRef nd; nd.x = (g_cf32*)gx; nd.y = (g_cf32*)gy; nd.z = (g_cf32*)gz; nd.m = (g_u8*)gm; nd.il = (g_u32*)gl; nd.n = n;
+        MaskPrm mp; mp.cx = mp.cy = mp.cz = 0.0f; mp.nx = mp.ny = 0.0f; mp.nz = 1.0f; mp.thr = z_th;
+        uint32_t count = w1_mask_pass(nd, kMaskSeed, mp).count;
+        if (count < 3) {
+            const Sel3 sel = w1_three_lowest(cx, s, n);
+            for (uint32_t i = lane; i < n; i += kFit1Threads) gm[i] = (i == sel.v[0] || i == sel.v[1] || i == sel.v[2]) ? 1 : 0;
+            // the index list in slot order: the three slots, ascending
+            uint32_t a = sel.v[0], b = sel.v[1], c = sel.v[2], t;
+            if (a > b) { t = a; a = b; b = t; }
+            if (b > c) { t = b; b = c; c = t; }
+            if (a > b) { t = a; a = b; b = t; }
+            if (lane == 0) { gl[0] = a; gl[1] = b; gl[2] = c; }
+            count = 3;
+        }
+        __syncthreads();                               // index list and mask bytes written by this wave: drain before the reads
+        float cs[3];                                   // centroid sums of the current mask
+        auto centroid_sweep = [&](uint32_t m) {
+            const Sums6 r = w1_chain_sweep(nd, m, kSweepXYZ, 1, no_prm, ring);
+            cx.addends += m;
+            cs[0] = r.v[0]; cs[1] = r.v[1]; cs[2] = r.v[2];
+        };
+        centroid_sweep(count);
+
+        // ---- iterative refit (recursive_patchwork.cpp:186-217) ------------------------------------
+        PlaneD pl; pl.cx = pl.cy = pl.cz = 0.0f; pl.nx = 0.0f; pl.ny = 0.0f; pl.nz = 1.0f; pl.residual = 3.402823466e+38f;
+        auto plane_of = [&](uint32_t m) {               // covariance sweep over the index list + eigenvector
+            const float fm = (float)m;
+            SweepPrm c; c.a = cs[0] / fm; c.b = cs[1] / fm; c.c = cs[2] / fm; c.d = c.e = c.f = 0.0f;
+            const Sums6 cv = w1_chain_sweep(nd, m, kSweepCov, 1, c, ring);
+            cx.addends += m;
+            const float fm1 = (float)(m - 1);
+            pl.cx = c.a; pl.cy = c.b; pl.cz = c.c;
+            const N3 nrm = w1_normal(cv.v[0] / fm1, cv.v[1] / fm1, cv.v[2] / fm1, cv.v[3] / fm1, cv.v[4] / fm1, cv.v[5] / fm1);
+            pl.nx = nrm.x; pl.ny = nrm.y; pl.nz = nrm.z;
+        };
+        auto residual_of = [&](uint32_t m) -> float {   // sum of |d| over the index list / m (recursive_patchwork.cpp:98-104)
+            SweepPrm q; q.a = pl.cx; q.b = pl.cy; q.c = pl.cz; q.d = pl.nx; q.e = pl.ny; q.f = pl.nz;
+            const Sums6 r = w1_chain_sweep(nd, m, kSweepDist, 1, q, ring);
+            cx.addends += m;
+            return r.v[0] / (float)m;
+        };
+        int iters = 0;
+        int final_bit = 0;
+        bool have_plane = false, have_residual = false;   // pl / pl.residual belong to exactly the final mask
+        bool list_is_final = true;                        // the index list holds the final mask's inliers
+        for (int iter = 0; iter < cfg.max_iter; ++iter) {
+            if (count < 3) break;
+            plane_of(count);
+            ++iters;
+            mp.cx = pl.cx; mp.cy = pl.cy; mp.cz = pl.cz; mp.nx = pl.nx; mp.ny = pl.ny; mp.nz = pl.nz; mp.thr = threshold;
+            const MaskOut mo = w1_mask_pass(nd, kMaskPlane, mp);
+            const uint32_t newcount = mo.count;
+            const bool any_changed = mo.changed != 0, any_differs_prev = mo.differs_prev != 0;
+            __syncthreads();
+            if (!any_changed) {                                  // new_mask == ground_mask: converged
+                pl.residual = residual_of(count);
+                have_plane = true; have_residual = true;
+                break;
+            }
+            const uint32_t oldcount = count;
+            count = newcount;
+            // Period-2 short cut (exact): the new mask equals the mask two iterations ago, so the loop would
+            // alternate between the two masks until max_iter; its outcome is decided by parity alone.
+            if (iter >= 1 && !any_differs_prev && newcount >= 3 && iter + 1 < cfg.max_iter) {
+                const int remaining = cfg.max_iter - (iter + 1);
+                iters = cfg.max_iter;
+                if (remaining & 1) {                             // ends on the older mask: pl was fitted on it
+                    final_bit = 1; count = oldcount;
+                    have_plane = true; list_is_final = false;    // its residual is computed below, over the older mask
+                } else {
+                    centroid_sweep(count);
+                }
+                break;
+            }
+            if (count >= 3) centroid_sweep(count);
+        }
+
+        // ---- final plane (recursive_patchwork.cpp:220-228) ----------------------------------------
+        if (count < 3) {
+            pl.cx = pl.cy = pl.cz = 0.0f; pl.nx = 0.0f; pl.ny = 0.0f; pl.nz = 1.0f; pl.residual = 3.402823466e+38f;
+        } else {
+            if (!have_plane) plane_of(count);                    // cs = sums of the final mask, the list holds it
+            if (!have_residual) {
+                if (!list_is_final) {                            // rebuild the list from the older mask (bit 1)
+                    (void)w1_mask_pass(nd, kMaskOlder, mp);
+                    __syncthreads();
+                }
+                pl.residual = residual_of(count);
+            }
+        }
+
+        // ---- split? (recursive_patchwork.cpp:231-305) ---------------------------------------------
+        const float split_threshold = cfg.th_dist * (1.0f + 1.5f * (float)depth);
+        const uint32_t min_patch = 50u + 10u * (uint32_t)depth;
+        if (pl.residual > split_threshold && depth < cfg.max_split_depth && n >= min_patch) {
+            const Sums6 m2 = w1_chain_sweep(nd, n, kSweepXY, 0, no_prm, ring);
+            const float fn = (float)n;
+            SweepPrm mean = no_prm; mean.a = m2.v[0] / fn; mean.b = m2.v[1] / fn;
+            const Sums6 v2 = w1_chain_sweep(nd, n, kSweepVarXY, 0, mean, ring);
+            cx.addends += 2ull * n;
+            const float var_x = v2.v[0] / fn, var_y = v2.v[1] / fn;
+            const int axis = (var_x > var_y) ? 0 : 1;
+            const float median = w1_select_rank(cx, s, n, axis, n / 2);
+            const float* src = axis == 0 ? gx : gy;
+            // stable partition: left = (val <= median) keeps order, then right keeps order (scratch: the list's array + ay, az)
+            uint32_t nleft = 0;
+            for (uint32_t b = 0; b < n; b += kWave) {
+                const uint32_t i = b + lane;
+                nleft += (uint32_t)__popcll(ballot64(i < n && src[i] <= median));
+            }
+            uint32_t lo = 0, ro = 0;
+            for (uint32_t b = 0; b < n; b += kWave) {
+                const uint32_t i = b + lane;
+                const bool ok = i < n;
+                const float val = ok ? src[i] : 0.0f;
+                const bool left = ok && val <= median;
+                const unsigned long long ml = ballot64(left), mr = ballot64(ok && !left);
+                if (ok) {
+                    const uint32_t d = cx.base + s + (left ? lo + (uint32_t)mbcnt64(ml) : nleft + ro + (uint32_t)mbcnt64(mr));
+                    p.ax[d] = gx[i]; p.ay[d] = gy[i]; p.az[d] = gz[i];
+                }
+                lo += (uint32_t)__popcll(ml); ro += (uint32_t)__popcll(mr);
+            }
+            __syncthreads();
+            for (uint32_t i = lane; i < n; i += kFit1Threads) {
+                const uint32_t g = cx.base + s + i;
+                p.sx[g] = p.ax[g]; p.sy[g] = p.ay[g]; p.sz[g] = p.az[g];
+            }
+            __syncthreads();
+            permuted = true;
+            pa.splits++;
+            pa.iters += (unsigned long long)iters;
+            emit_node(p, lane, frame, patch, depth, s, n, RPW_NODE_SPLIT, iters, count, axis, median, &pl);
+            const uint32_t nright = n - nleft;
+            if (lane == 0) {
+                const bool left_small = nleft <= nright;
+                const uint32_t big_s = left_small ? s + nleft : s, big_n = left_small ? nright : nleft;
+                const uint32_t sm_s = left_small ? s : s + nleft, sm_n = left_small ? nleft : nright;
+                stk[3 * sp] = big_s; stk[3 * sp + 1] = big_n; stk[3 * sp + 2] = (uint32_t)(depth + 1);
+                stk[3 * (sp + 1)] = sm_s; stk[3 * (sp + 1) + 1] = sm_n; stk[3 * (sp + 1) + 2] = (uint32_t)(depth + 1);
+            }
+            sp += 2;
+            __syncthreads();
+            continue;
+        }
+
+        // ---- FIT leaf: labels (and residuals) -----------------------------------------------------
+        pa.iters += (unsigned long long)iters;
+        for (uint32_t i0 = lane; i0 < n; i0 += 4 * kFit1Threads) {
+            uint32_t orig[4], m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * kFit1Threads, ic = i < n ? i : n - 1u; orig[u] = gi[ic]; m[u] = gm[ic]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * kFit1Threads;
+                if (i >= n) continue;
+                p.labels[fo + orig[u]] = ((m[u] >> final_bit) & 1u) ? RPW_LABEL_GROUND : RPW_LABEL_NONGROUND;
+                if (p.residual) {
+                    float x, y, z;
+                    if (permuted) {
+                        P3 q = load_point(p, fo + orig[u]);
+                        if (p.sensors.n) (void)fuse_point(p, (uint32_t)frame, orig[u], q);
+                        x = q.x; y = q.y; z = q.z;
+                    }
+                    else { x = gx[i]; y = gy[i]; z = gz[i]; }
+                    p.residual[fo + orig[u]] = plane_dist(x, y, z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
+                }
+            }
+        }
+        pa.ground += count;
+        emit_node(p, lane, frame, patch, depth, s, n, RPW_NODE_FIT, iters, count, -1, 0.0f, &pl);
+    }
+
+    if (lane == 0) {
+        rpw_frame_stats* st = p.stats + frame;
+        atomicAdd((unsigned long long*)&st->chain_addends, cx.addends);
+        atomicAdd(&st->n_ground, pa.ground);
+        atomicAdd(&st->n_nodes, pa.nodes);
+        atomicAdd(&st->n_splits, pa.splits);
+        atomicMax(&st->max_depth, pa.maxdepth);
+        atomicAdd((unsigned long long*)&st->total_iterations, pa.iters);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // debug kernels (test hooks)
 // ------------------------------------------------------------------------------------------
@@ -1173,6 +1922,40 @@ __global__ void debug_eig3_kernel(const float* cov, float* nrm, uint32_t n)
         smallest_eigenvector(A[0], A[3], A[4], A[6], A[7], A[8], nx, ny, nz);
         nrm[3 * (size_t)i] = nx; nrm[3 * (size_t)i + 1] = ny; nrm[3 * (size_t)i + 2] = nz;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-pointer pipeline helpers: a frame in a pipeline slot is processed by kernels only (no copy-engine
+// operation sits between two frames' kernels): its input is read in place from pinned host memory by bin_tile,
+// and its results are written to pinned host memory by frame_copy_out.
+// ------------------------------------------------------------------------------------------
+// frame offsets / tile bases of a one-frame batch, and the zeroed control words (bucket counts, node count, class totals)
+__global__ __launch_bounds__(256) void frame_setup_kernel(uint32_t* offsets, uint32_t n, uint32_t tiles, uint32_t* ctrl, uint32_t ctrl_words)
+{
+    const uint32_t i = threadIdx.x;
+    if (i == 0) { offsets[0] = 0; offsets[1] = n; offsets[2] = 0; offsets[3] = tiles; }
+    for (uint32_t j = i; j < ctrl_words; j += blockDim.x) ctrl[j] = 0;
+}
+
+// labels (and residuals, and the stats record) of one frame: device memory -> pinned host memory, 16 bytes per lane
+__global__ __launch_bounds__(256) void frame_copy_out_kernel(const uint8_t* __restrict__ labels, uint8_t* __restrict__ h_labels, uint32_t n,
+                                                             const float* __restrict__ res, float* __restrict__ h_res,
+                                                             const rpw_frame_stats* __restrict__ stats, rpw_frame_stats* __restrict__ h_stats)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    const uint32_t n16 = n / 16u;
+    const uint4* src = reinterpret_cast<const uint4*>(labels);
+    uint4* dst = reinterpret_cast<uint4*>(h_labels);
+    for (uint32_t i = tid; i < n16; i += nthreads) dst[i] = src[i];
+    for (uint32_t i = n16 * 16u + tid; i < n; i += nthreads) h_labels[i] = labels[i];
+    if (res) {
+        const uint32_t r4 = n / 4u;
+        const float4* rs = reinterpret_cast<const float4*>(res);
+        float4* rd = reinterpret_cast<float4*>(h_res);
+        for (uint32_t i = tid; i < r4; i += nthreads) rd[i] = rs[i];
+        for (uint32_t i = r4 * 4u + tid; i < n; i += nthreads) h_res[i] = res[i];
+    }
+    if (tid == 0) *h_stats = *stats;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1197,11 +1980,30 @@ void launch_scan(const DevParams& p, hipStream_t s)
     int parts = kScanThreads / (p.P + 4); if (parts > 16) parts = 16; if (parts < 1) parts = 1;      // as in the kernel
     hipLaunchKernelGGL(scan_offsets_kernel, dim3(p.frame_count), dim3(kScanThreads), (size_t)p.PB * (2 + parts) * 4, s, p);
 }
+// RPW_FIT=2 selects the two-wave producer / consumer kernel, anything else the single-wave kernel (A/B measurements)
+static int fit_variant()
+{
+    static const int v = [] { const char* e = getenv("RPW_FIT"); return (e && e[0] == '2') ? 2 : 1; }();
+    return v;
+}
 void launch_fit(const DevParams& p, hipStream_t s)
 {
     const uint32_t grid = p.n_frames * (uint32_t)p.P;
     if (grid == 0) return;
-    hipLaunchKernelGGL(patch_fit_kernel, dim3(grid), dim3(kFitThreads), 0, s, p);
+    if (fit_variant() == 1) hipLaunchKernelGGL(patch_fit1_kernel, dim3(grid), dim3(kFit1Threads), 0, s, p);
+    else                    hipLaunchKernelGGL(patch_fit_kernel, dim3(grid), dim3(kFitThreads), 0, s, p);
+}
+void launch_frame_setup(uint32_t* offsets, uint32_t n, uint32_t tiles, uint32_t* ctrl, uint32_t ctrl_words, hipStream_t s)
+{
+    hipLaunchKernelGGL(frame_setup_kernel, dim3(1), dim3(256), 0, s, offsets, n, tiles, ctrl, ctrl_words);
+}
+void launch_frame_copy_out(const uint8_t* labels, uint8_t* h_labels, uint32_t n, const float* res, float* h_res,
+                           const rpw_frame_stats* stats, rpw_frame_stats* h_stats, hipStream_t s)
+{
+    uint32_t blocks = (n / 16u + 255u) / 256u;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(frame_copy_out_kernel, dim3(blocks), dim3(256), 0, s, labels, h_labels, n, res, h_res, stats, h_stats);
 }
 void launch_debug_angles(const float* x, const float* y, float* a, uint32_t n, hipStream_t s)
 {

@@ -31,7 +31,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", rpw_amd.LIB_PATH], text=True)
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
     assert set(syms) <= exported
-    assert lib.rpw_abi_version() == 1
+    assert lib.rpw_abi_version() == 2
 
 
 def test_no_oracle_linked_into_product():
@@ -109,10 +109,36 @@ def test_atan2f_model_is_libm_bit_for_bit():
 
 
 def test_capacity_limit_is_checked_before_the_device_is_touched():
-    """max_points above 2^30 is refused (32-bit byte offsets inside the kernels); on this CPU box the device check comes first."""
+    """max_points above 2^30 is refused (32-bit byte offsets inside the kernels) BEFORE any device query: also here, without a GPU."""
     lib = rpw_amd.load_library()
     h = C.c_void_p()
     c = rpw_amd.PatchworkConfig().to_c()
     st = lib.rpw_create(C.byref(c), 0, (1 << 30) + 1, 1, C.byref(h))
-    assert st != 0 and not h.value
-    assert lib.rpw_last_error(None)
+    assert st == 4 and not h.value                                              # RPW_ERR_CAPACITY
+    assert b"1073741824" in lib.rpw_last_error(None)
+
+
+def test_pipeline_entry_points_reject_a_null_handle():
+    """rpw_submit / rpw_wait / rpw_poll / rpw_set_pipeline: status codes, no crash, without a device."""
+    lib = rpw_amd.load_library()
+    done = C.c_int(0)
+    assert lib.rpw_set_pipeline(None, 4) == 1                                   # RPW_ERR_INVALID
+    assert lib.rpw_submit(None, 0, None, 0, 0) == 1
+    assert lib.rpw_submit_pointcloud2(None, 0, None, 0, 16, 0, 4, 8, 0) == 1
+    assert lib.rpw_poll(None, 0, C.byref(done)) == 1
+    assert lib.rpw_wait(None, 0, None, None, None) == 1
+    assert lib.rpw_get_pipeline(None) == 0
+    assert not lib.rpw_slot_input(None, 0)
+
+
+def test_library_sets_hw_queue_default_without_overriding(monkeypatch):
+    """Loading the library leaves a user-set GPU_MAX_HW_QUEUES alone and sets 16 otherwise (streams of pipeline slots
+    need hardware queues of their own). Checked in child processes: the variable is read at load time."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    # getenv through libc sees what setenv() did (os.environ is a snapshot taken at interpreter start)
+    probe = ("import ctypes; ctypes.CDLL(%r); g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p; "
+             "print(g(b'GPU_MAX_HW_QUEUES').decode())" % rpw_amd.LIB_PATH)
+    assert subprocess.check_output([sys.executable, "-c", probe], env=env, text=True).strip() == "16"
+    env["GPU_MAX_HW_QUEUES"] = "5"
+    assert subprocess.check_output([sys.executable, "-c", probe], env=env, text=True).strip() == "5"
