@@ -25,6 +25,7 @@ thread_local std::string g_create_error;
 __attribute__((constructor)) void rpw_runtime_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 constexpr int kStageSlots = 8;
+constexpr int kSweepRangeMode = 3;   // kSweepRange of rpw_kernels.hip (sweeps over every slot of the node, not over the index list)
 
 struct EventPair { int kernel; hipEvent_t a, b; };
 
@@ -877,6 +878,62 @@ rpw_status rpw_debug_eig3(rpw_handle* h, const float* cov9, float* normal3, uint
     RPW_HIP(h, hipStreamSynchronize(nullptr));
     RPW_HIP(h, hipMemcpy(normal3, dn, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     (void)hipFree(dc); (void)hipFree(dn);
+    return RPW_OK;
+}
+
+rpw_status rpw_debug_loop_bench(rpw_handle* h, int what, uint32_t n, uint32_t inlier_pct, int reps, uint32_t blocks, double* ms)
+{
+    if (!h || !ms || n == 0 || blocks == 0 || reps <= 0 || inlier_pct > 100) return RPW_ERR_INVALID;
+    if ((uint64_t)n * blocks > (1ull << 28)) return fail(h, RPW_ERR_CAPACITY, "loop bench: n * blocks too large");
+    if (!((what >= 0 && what <= 5) || (what >= 16 && what <= 18))) return fail(h, RPW_ERR_INVALID, "loop bench: unknown loop %d", what);
+    RPW_HIP(h, hipSetDevice(h->device));
+    const size_t total = (size_t)n * blocks;
+    // synthetic node: a plane z ~ 0 with noise and 1 - inlier_pct % of points well above it; the index list holds the inliers
+    std::vector<float> x(n), y(n), z(n); std::vector<uint32_t> il(n); std::vector<uint8_t> m(n);
+    uint32_t count = 0; uint32_t seed = 12345u;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (float)(seed >> 8) * (1.0f / 16777216.0f); };
+    for (uint32_t i = 0; i < n; ++i) {
+        x[i] = 20.0f + 10.0f * rnd(); y[i] = -5.0f + 10.0f * rnd();
+        const bool in = (uint32_t)(rnd() * 100.0f) < inlier_pct;
+        z[i] = in ? 0.02f * (rnd() - 0.5f) : 1.0f + rnd();
+        m[i] = in ? 1 : 0;
+        if (in) il[count++] = i;
+    }
+    if (count == 0) { il[0] = 0; count = 1; }
+    float *dx = nullptr, *dy = nullptr, *dz = nullptr, *dout = nullptr; uint8_t* dm = nullptr; uint32_t* dil = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dz); (void)hipFree(dout); (void)hipFree(dm); (void)hipFree(dil); };
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc(&dx, total * 4);
+    if (e == hipSuccess) e = hipMalloc(&dy, total * 4);
+    if (e == hipSuccess) e = hipMalloc(&dz, total * 4);
+    if (e == hipSuccess) e = hipMalloc(&dil, total * 4);
+    if (e == hipSuccess) e = hipMalloc(&dm, total);
+    if (e == hipSuccess) e = hipMalloc(&dout, (size_t)blocks * 4);
+    for (uint32_t b = 0; e == hipSuccess && b < blocks; ++b) {
+        e = hipMemcpy(dx + (size_t)b * n, x.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dy + (size_t)b * n, y.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dz + (size_t)b * n, z.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dil + (size_t)b * n, il.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dm + (size_t)b * n, m.data(), (size_t)n, hipMemcpyHostToDevice);
+    }
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&ea);
+    if (e == hipSuccess) e = hipEventCreate(&eb);
+    float t = 0.0f;
+    if (e == hipSuccess) {
+        const uint32_t cnt = what < 16 ? (what == kSweepRangeMode || what >= 4 ? n : count) : n;
+        launch_loop_bench(dx, dy, dz, dm, dil, n, cnt, what, 1, blocks, dout, nullptr);            // warm-up
+        e = hipEventRecord(ea, nullptr);
+        launch_loop_bench(dx, dy, dz, dm, dil, n, cnt, what, reps, blocks, dout, nullptr);
+        if (e == hipSuccess) e = hipEventRecord(eb, nullptr);
+        if (e == hipSuccess) e = hipEventSynchronize(eb);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, ea, eb);
+    }
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    cleanup();
+    if (e != hipSuccess) return fail(h, RPW_ERR_HIP, "loop bench: %s", hipGetErrorString(e));
+    *ms = (double)t;
     return RPW_OK;
 }
 

@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
 // executed by 64 lanes. Sums are accumulated in exactly the reference's order (recursive_patchwork.cpp:98-104,
 // 383-387, 241-248; point_cloud_processor.cpp:63-67, 78-83).
 // ==========================================================================================
-constexpr int kW1Ring = 2;
+constexpr int kW1Ring = 3;           // ring slots: slot u lives in ring slot u % 3, a compile-time constant inside the loop unrolled by three
 
 struct Fit1Shared {
     union {                            // the gather prologue is over before the first chain sweep
@@ -1222,14 +1222,28 @@ __device__ __forceinline__ float ldg_f32(g_cf32* base, uint32_t slot)
     return *reinterpret_cast<g_cf32*>(reinterpret_cast<__attribute__((address_space(1))) const char*>(base) + slot * 4u);
 }
 
-// slot min(i, n-1) of the node, raw: lanes past the end read the last slot again (never used)
-__device__ __forceinline__ P4 w1_load(const NodeRef& nd, int lane, uint32_t chunk)
+// Arguments of a real function arrive in vector registers; everything a pass gets is wave-uniform, and saying so
+// (v_readfirstlane) turns its loops into scalar loops and its loads into the SGPR-base + 32-bit-offset form.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float uni(float v) { return __uint_as_float(uni(__float_as_uint(v))); }
+template <class T> __device__ __forceinline__ T* uni_ptr(T* p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned long long u = ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | (unsigned long long)uni((uint32_t)v);
+    return (T*)u;
+}
+__device__ __forceinline__ NodeRef uni(NodeRef nd)
+{
+    nd.x = uni_ptr(nd.x); nd.y = uni_ptr(nd.y); nd.z = uni_ptr(nd.z); nd.m = uni_ptr(nd.m); nd.il = uni_ptr(nd.il); nd.n = uni(nd.n);
+    return nd;
+}
+
+// slot i of the node, raw (i < n)
+__device__ __forceinline__ P4 w1_load(const NodeRef& nd, uint32_t i)
 {
     P4 r;
-    const uint32_t i = chunk * kWave + lane;
-    const uint32_t g = i < nd.n ? i : nd.n - 1u;
-    r.x = ldg_f32(nd.x, g); r.y = ldg_f32(nd.y, g); r.z = ldg_f32(nd.z, g);
-    r.m = (uint32_t)nd.m[g];
+    r.x = ldg_f32(nd.x, i); r.y = ldg_f32(nd.y, i); r.z = ldg_f32(nd.z, i);
+    r.m = (uint32_t)nd.m[i];
     return r;
 }
 
@@ -1238,53 +1252,97 @@ __device__ __forceinline__ P4 w1_load(const NodeRef& nd, int lane, uint32_t chun
 //   kMaskSeed   inlier = z < prm.thr                      byte := inlier
 //   kMaskPlane  inlier = |(p - c) . n| < prm.thr          byte := inlier | history << 1; flags: changed / differs from the mask before
 //   kMaskOlder  inlier = bit 1 of the byte (the mask one iteration back); the byte is left alone
+// The list has one entry per slot of the node: inliers fill it from the front in slot order, the others fill it from the
+// back -- so every lane stores exactly one entry per chunk and the loop over the full chunks is ONE basic block (a
+// conditional store is a branch around it, and a loop with branches gets a full s_waitcnt vmcnt(0) at its head: the
+// four-chunk prefetch then hides nothing). Only the last, partial chunk is handled with conditions.
 enum { kMaskSeed = 0, kMaskPlane = 1, kMaskOlder = 2 };
 struct MaskPrm { float cx, cy, cz, nx, ny, nz, thr; };
 struct MaskOut { uint32_t count, changed, differs_prev; };
 
-__device__ __attribute__((noinline)) MaskOut w1_mask_pass(NodeRef nd, int mode, MaskPrm prm)
+struct yes { static constexpr bool value = true; };
+struct no { static constexpr bool value = false; };
+
+template <int MODE>
+__device__ __forceinline__ MaskOut w1_mask_loop(const NodeRef& nd, const MaskPrm& prm, int lane)
 {
-    const int lane = threadIdx.x;
-    uint32_t cursor = 0;
-    const uint32_t n = nd.n;
-    const uint32_t nch = (n + kWave - 1) / kWave;
     typedef __attribute__((address_space(1))) char g_char;
     g_char* il = reinterpret_cast<g_char*>(nd.il);
+    const uint32_t n = nd.n;
+    const uint32_t nfull = n / kWave;                              // chunks with all 64 slots
+    uint32_t cursor = 0;                                           // inliers so far
     bool changed = false, differs_prev = false;
-    P4 r0 = w1_load(nd, lane, 0), r1 = w1_load(nd, lane, 1), r2 = w1_load(nd, lane, 2), r3 = w1_load(nd, lane, 3);
-    for (uint32_t c = 0; c < nch; c += 4) {                       // four register sets, each reloaded right after use
-#define RPW_W1_MASK_STEP(R, CC)                                                                             \
-        if ((CC) < nch) {                                                                                   \
-            const uint32_t i = (CC) * kWave + lane;                                                         \
-            const bool ok = i < n;                                                                          \
-            bool in;                                                                                        \
-            if (mode == kMaskPlane) {                                                                       \
-                const float d = plane_dist(R.x, R.y, R.z, prm.cx, prm.cy, prm.cz, prm.nx, prm.ny, prm.nz); \
-                in = d < prm.thr;                                                                           \
-                const bool old = R.m & 1u, prev = (R.m >> 1) & 1u;                                         \
-                changed |= ok && (in != old);                                                               \
-                differs_prev |= ok && (in != prev);                                                         \
-                if (ok) nd.m[i] = (uint8_t)((in ? 1u : 0u) | ((R.m & 0x7fu) << 1));                       \
-            } else if (mode == kMaskSeed) {                                                                 \
-                in = R.z < prm.thr;                                                                         \
-                if (ok) nd.m[i] = in ? 1 : 0;                                                               \
-            } else {                                                                                        \
-                in = (R.m >> 1) & 1u;                                                                       \
-            }                                                                                               \
-            in = in && ok;                                                                                  \
-            const unsigned long long m = ballot64(in);                                                      \
-            if (in) *reinterpret_cast<g_u32*>(il + (cursor + (uint32_t)mbcnt64(m)) * 4u) = i;              \
-            cursor += (uint32_t)__popcll(m);                                                                \
-            R = w1_load(nd, lane, (CC) + 4);                                                                \
+    // one chunk: predicate, history byte, list entry. FULL: all 64 lanes hold a slot.
+    auto step = [&](const P4& r, uint32_t c, auto full) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full)::value;
+        const uint32_t i = c * kWave + lane;
+        const bool ok = FULL || i < n;
+        bool in;
+        if (MODE == kMaskPlane) {
+            const float d = plane_dist(r.x, r.y, r.z, prm.cx, prm.cy, prm.cz, prm.nx, prm.ny, prm.nz);
+            in = d < prm.thr;
+            const bool old = r.m & 1u, prev = (r.m >> 1) & 1u;
+            changed |= ok && (in != old);
+            differs_prev |= ok && (in != prev);
+            const uint8_t nb = (uint8_t)((in ? 1u : 0u) | ((r.m & 0x7fu) << 1));
+            if (FULL) nd.m[i] = nb; else if (ok) nd.m[i] = nb;
+        } else if (MODE == kMaskSeed) {
+            in = r.z < prm.thr;
+            if (FULL) nd.m[i] = in ? 1 : 0; else if (ok) nd.m[i] = in ? 1 : 0;
+        } else {
+            in = (r.m >> 1) & 1u;
         }
-        RPW_W1_MASK_STEP(r0, c) RPW_W1_MASK_STEP(r1, c + 1) RPW_W1_MASK_STEP(r2, c + 2) RPW_W1_MASK_STEP(r3, c + 3)
-#undef RPW_W1_MASK_STEP
+        in = in && ok;
+        const unsigned long long m = ballot64(in);
+        const uint32_t rank = (uint32_t)mbcnt64(m);                // inliers among the lower lanes
+        // an inlier goes to cursor + rank; slot i as a non-inlier is number (i - cursor - rank) of them and goes to
+        // n - 1 - that (the tail of the list is never read)
+        const uint32_t pos = in ? cursor + rank : (n - 1u) - (i - cursor - rank);
+        if (FULL) *reinterpret_cast<g_u32*>(il + pos * 4u) = i;
+        else if (ok) *reinterpret_cast<g_u32*>(il + pos * 4u) = i;
+        cursor += (uint32_t)__popcll(m);
+    };
+    // full chunks, four register sets, each reloaded right after use; chunks past the last full one are not loaded
+    uint32_t c = 0;
+    if (nfull >= 4) {
+        P4 r0 = w1_load(nd, 0 * kWave + lane), r1 = w1_load(nd, 1 * kWave + lane), r2 = w1_load(nd, 2 * kWave + lane), r3 = w1_load(nd, 3 * kWave + lane);
+        const uint32_t lastfull = (nfull - 1u) * kWave;
+        for (; c + 4 <= nfull; c += 4) {
+            // (the reloads clamp to the last full chunk: loads past it would be wasted, never wrong)
+            const uint32_t b4 = (c + 4) * kWave, b5 = b4 + kWave, b6 = b5 + kWave, b7 = b6 + kWave;
+            step(r0, c, yes());     r0 = w1_load(nd, (b4 < lastfull ? b4 : lastfull) + lane);
+            step(r1, c + 1, yes()); r1 = w1_load(nd, (b5 < lastfull ? b5 : lastfull) + lane);
+            step(r2, c + 2, yes()); r2 = w1_load(nd, (b6 < lastfull ? b6 : lastfull) + lane);
+            step(r3, c + 3, yes()); r3 = w1_load(nd, (b7 < lastfull ? b7 : lastfull) + lane);
+        }
+    }
+    for (; c < nfull; ++c) {                                       // up to three full chunks left
+        const P4 r = w1_load(nd, c * kWave + lane);
+        step(r, c, yes());
+    }
+    if (nfull * kWave < n) {                                       // the partial chunk
+        const uint32_t i = nfull * kWave + lane;
+        const P4 r = w1_load(nd, i < n ? i : n - 1u);
+        step(r, nfull, no());
     }
     MaskOut o;
     o.count = cursor;
     o.changed = ballot64(changed) != 0ull ? 1u : 0u;
     o.differs_prev = ballot64(differs_prev) != 0ull ? 1u : 0u;
     return o;
+}
+
+__device__ __attribute__((noinline)) MaskOut w1_mask_pass(NodeRef nd_in, int mode, MaskPrm prm)
+{
+    const int lane = threadIdx.x;
+    const NodeRef nd = uni(nd_in);
+    prm.cx = uni(prm.cx); prm.cy = uni(prm.cy); prm.cz = uni(prm.cz); prm.nx = uni(prm.nx); prm.ny = uni(prm.ny); prm.nz = uni(prm.nz);
+    prm.thr = uni(prm.thr);
+    switch (uni((uint32_t)mode)) {
+    case kMaskPlane: return w1_mask_loop<kMaskPlane>(nd, prm, lane);
+    case kMaskSeed:  return w1_mask_loop<kMaskSeed>(nd, prm, lane);
+    default:         return w1_mask_loop<kMaskOlder>(nd, prm, lane);
+    }
 }
 
 struct X3 { float x, y, z; };
@@ -1335,6 +1393,7 @@ __device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count
     // addends of one element, in two halves (so that they can sit in two different steps)
     float v[6];
     f2 dxy; float dz;
+    X3 P1, P2, P0;
     auto make_a = [&](const X3& q) __attribute__((always_inline)) {
         if (MODE == kSweepCov) {
             // two-wide float arithmetic (v_pk_add_f32 / v_pk_mul_f32: each half is an ordinary IEEE binary32 operation)
@@ -1358,8 +1417,8 @@ __device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count
     // rows [k0, k1) of slot u into ring slot u & 1 (row k at k * kLdw, column = lane); columns past the end get -0.0f,
     // the exact additive identity (a select, not a branch: the loop body must stay ONE basic block, or the adds
     // are sunk out of their steps)
-    auto put = [&](uint32_t u, int k0, int k1) __attribute__((always_inline)) {
-        lds_f32* dst = ring + (u & (kW1Ring - 1)) * kSlotFloats + lane;
+    auto put = [&](uint32_t u, int rs, int k0, int k1) __attribute__((always_inline)) {
+        lds_f32* dst = ring + rs * kSlotFloats + lane;
         const bool live = u * kWave + lane < count;
 #pragma unroll
         for (int k = k0; k < k1 && k < K; ++k) dst[k * kLdw] = live ? v[k] : -0.0f;
@@ -1368,11 +1427,15 @@ __device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count
     // Three register sets each, used round robin and reloaded right after use (the loop is unrolled by three): nothing
     // is ever copied, so no instruction touches a value that has just been requested from memory.
     //   P[u % 3] holds the points of slot u; I[u % 3] the indices of slot u.
+    // (prologue in the loop's own order -- indices first, then the points, slot 0 first -- so that the loop is entered
+    // with the same kind of loads in flight as its back edge carries; entered with none, its first wait became vmcnt(0))
+    const uint32_t j0 = index_of(0), j1 = index_of(1), j2 = index_of(2), j3 = index_of(3);
     uint32_t I1 = index_of(4), I2 = index_of(5), I0 = 0;
-    X3 P1 = point_of(index_of(1)), P2 = point_of(index_of(2)), P0 = point_of(index_of(3));
     {
-        const X3 p0 = point_of(index_of(0));
-        make_a(p0); make_b(); put(0, 0, 6);
+        const X3 p0 = point_of(j0);
+        X3 q1 = point_of(j1), q2 = point_of(j2), q3 = point_of(j3);
+        make_a(p0); make_b(); put(0, 0, 0, 6);
+        P1 = q1; P2 = q2; P0 = q3;
     }
     const int row = lane < K ? lane : K - 1;
     const lds_f32* rowp = ring + row * kLdw;
@@ -1383,15 +1446,15 @@ __device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count
 #define RPW_W1_STEP_B(Q, FILL) { B[Q] = *reinterpret_cast<const lds_f4*>(cur + 4 * (Q)); RPW_CHAIN4(acc, A[Q]) FILL; __builtin_amdgcn_sched_barrier(0); }
 #define RPW_W1_STEP_A(Q, FILL) { A[Q] = *reinterpret_cast<const lds_f4*>(nxt + 4 * (Q)); RPW_CHAIN4(acc, B[Q]) FILL; __builtin_amdgcn_sched_barrier(0); }
     // slot T: P_CUR holds slot T + 1 and is reloaded with slot T + 4 (indices I_USE); I_LOAD receives the indices of slot T + 6
-#define RPW_W1_SLOT(T, P_CUR, I_USE, I_LOAD) {                                                              \
-        const lds_f32* cur = rowp + ((T) & (kW1Ring - 1)) * kSlotFloats + 32;                               \
-        const lds_f32* nxt = rowp + (((T) + 1) & (kW1Ring - 1)) * kSlotFloats;                              \
+#define RPW_W1_SLOT(T, RS, P_CUR, I_USE, I_LOAD) {                                                          \
+        const lds_f32* cur = rowp + (RS) * kSlotFloats + 32;                                                \
+        const lds_f32* nxt = rowp + (((RS) + 1) % kW1Ring) * kSlotFloats;                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         RPW_W1_STEP_B(0, make_a(P_CUR))                                                                     \
         RPW_W1_STEP_B(1, make_b())                                                                          \
-        RPW_W1_STEP_B(2, put((T) + 1, 0, 2))                                                                \
-        RPW_W1_STEP_B(3, put((T) + 1, 2, 4))                                                                \
-        RPW_W1_STEP_B(4, put((T) + 1, 4, 6))                                                                \
+        RPW_W1_STEP_B(2, put((T) + 1, ((RS) + 1) % kW1Ring, 0, 2))                                          \
+        RPW_W1_STEP_B(3, put((T) + 1, ((RS) + 1) % kW1Ring, 2, 4))                                          \
+        RPW_W1_STEP_B(4, put((T) + 1, ((RS) + 1) % kW1Ring, 4, 6))                                          \
         RPW_W1_STEP_B(5, (void)0)                                                                           \
         RPW_W1_STEP_B(6, (void)0)                                                                           \
         RPW_W1_STEP_B(7, (void)0)                                                                           \
@@ -1405,11 +1468,11 @@ __device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count
         RPW_W1_STEP_A(7, (void)0)                                                                           \
     }
     for (uint32_t t = 0; t < nslots; t += 3) {
-        RPW_W1_SLOT(t, P1, I1, I0)
+        RPW_W1_SLOT(t, 0, P1, I1, I0)
         if (t + 1 >= nslots) break;
-        RPW_W1_SLOT(t + 1, P2, I2, I1)
+        RPW_W1_SLOT(t + 1, 1, P2, I2, I1)
         if (t + 2 >= nslots) break;
-        RPW_W1_SLOT(t + 2, P0, I0, I2)
+        RPW_W1_SLOT(t + 2, 2, P0, I0, I2)
     }
 #undef RPW_W1_SLOT
 #undef RPW_W1_STEP_A
@@ -1417,9 +1480,13 @@ __device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count
     return acc;
 }
 
-__device__ __attribute__((noinline)) Sums6 w1_chain_sweep(NodeRef nd, uint32_t count, int mode, int indexed, SweepPrm prm, lds_f32* ring)
+__device__ __attribute__((noinline)) Sums6 w1_chain_sweep(NodeRef nd_in, uint32_t count, int mode, int indexed, SweepPrm prm, lds_f32* ring)
 {
     const int lane = threadIdx.x;
+    const NodeRef nd = uni(nd_in);
+    count = uni(count);
+    prm.a = uni(prm.a); prm.b = uni(prm.b); prm.c = uni(prm.c); prm.d = uni(prm.d); prm.e = uni(prm.e); prm.f = uni(prm.f);
+    ring = (lds_f32*)(uintptr_t)uni((uint32_t)(uintptr_t)ring);
     Sums6 out;
 #pragma unroll
     for (int k = 0; k < 6; ++k) out.v[k] = 0.0f;
@@ -1603,6 +1670,7 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
 {
     __shared__ Fit1Shared sh;
     const int lane = threadIdx.x;
+#define W1_PH(IDX, CNT, ...) { __VA_ARGS__; }
 
     // ---- block -> patch, largest size bucket first --------------------------------------------
     uint32_t linear;
@@ -1633,7 +1701,8 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         g.goff = p.hist + (size_t)t0 * p.PB + patch; g.gdir = p.tdir + (size_t)t0 * p.PB + patch; g.tp = p.tp;
         g.sx = p.sx; g.sy = p.sy; g.sz = p.sz; g.sidx = p.sidx;
         g.nt = p.tile_base[frame + 1] - t0; g.PB = (uint32_t)p.PB; g.fo = fo; g.begin = pd.begin; g.n = pd.n;
-        const Box6 b = w1_gather(g, (lds_word*)sh.dir.toff, (lds_word*)sh.dir.tsrc);
+        Box6 b;
+        W1_PH(0, pd.n, b = w1_gather(g, (lds_word*)sh.dir.toff, (lds_word*)sh.dir.tsrc))
 #pragma unroll
         for (int k = 0; k < 6; ++k) rootbox[k] = b.v[k];
         __syncthreads();                               // the directory's LDS becomes the ring; the wave's own stores are ordered
@@ -1652,7 +1721,8 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
     {
         NodeRef root; root.x = (g_cf32*)(p.sx + cx.base); root.y = (g_cf32*)(p.sy + cx.base); root.z = (g_cf32*)(p.sz + cx.base);
         root.m = (g_u8*)(p.mask + cx.base); root.il = (g_u32*)(cx.il + cx.base); root.n = pd.n;
-        const Sums6 sum = w1_chain_sweep(root, pd.n, kSweepRange, 0, no_prm, ring);
+        Sums6 sum;
+        W1_PH(1, pd.n, sum = w1_chain_sweep(root, pd.n, kSweepRange, 0, no_prm, ring))
         cx.addends += pd.n;
         mean_dist = sum.v[0] / (float)pd.n;
     }
@@ -1723,7 +1793,8 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         }
         NodeRef nd; nd.x = (g_cf32*)gx; nd.y = (g_cf32*)gy; nd.z = (g_cf32*)gz; nd.m = (g_u8*)gm; nd.il = (g_u32*)gl; nd.n = n;
         MaskPrm mp; mp.cx = mp.cy = mp.cz = 0.0f; mp.nx = mp.ny = 0.0f; mp.nz = 1.0f; mp.thr = z_th;
-        uint32_t count = w1_mask_pass(nd, kMaskSeed, mp).count;
+        uint32_t count;
+        W1_PH(2, n, count = w1_mask_pass(nd, kMaskSeed, mp).count)
         if (count < 3) {
             const Sel3 sel = w1_three_lowest(cx, s, n);
             for (uint32_t i = lane; i < n; i += kFit1Threads) gm[i] = (i == sel.v[0] || i == sel.v[1] || i == sel.v[2]) ? 1 : 0;
@@ -1738,7 +1809,8 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         __syncthreads();                               // index list and mask bytes written by this wave: drain before the reads
         float cs[3];                                   // centroid sums of the current mask
         auto centroid_sweep = [&](uint32_t m) {
-            const Sums6 r = w1_chain_sweep(nd, m, kSweepXYZ, 1, no_prm, ring);
+            Sums6 r;
+            W1_PH(3, m, r = w1_chain_sweep(nd, m, kSweepXYZ, 1, no_prm, ring))
             cx.addends += m;
             cs[0] = r.v[0]; cs[1] = r.v[1]; cs[2] = r.v[2];
         };
@@ -1749,16 +1821,19 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         auto plane_of = [&](uint32_t m) {               // covariance sweep over the index list + eigenvector
             const float fm = (float)m;
             SweepPrm c; c.a = cs[0] / fm; c.b = cs[1] / fm; c.c = cs[2] / fm; c.d = c.e = c.f = 0.0f;
-            const Sums6 cv = w1_chain_sweep(nd, m, kSweepCov, 1, c, ring);
+            Sums6 cv;
+            W1_PH(4, m, cv = w1_chain_sweep(nd, m, kSweepCov, 1, c, ring))
             cx.addends += m;
             const float fm1 = (float)(m - 1);
             pl.cx = c.a; pl.cy = c.b; pl.cz = c.c;
-            const N3 nrm = w1_normal(cv.v[0] / fm1, cv.v[1] / fm1, cv.v[2] / fm1, cv.v[3] / fm1, cv.v[4] / fm1, cv.v[5] / fm1);
+            N3 nrm;
+            W1_PH(5, 1, nrm = w1_normal(cv.v[0] / fm1, cv.v[1] / fm1, cv.v[2] / fm1, cv.v[3] / fm1, cv.v[4] / fm1, cv.v[5] / fm1))
             pl.nx = nrm.x; pl.ny = nrm.y; pl.nz = nrm.z;
         };
         auto residual_of = [&](uint32_t m) -> float {   // sum of |d| over the index list / m (recursive_patchwork.cpp:98-104)
             SweepPrm q; q.a = pl.cx; q.b = pl.cy; q.c = pl.cz; q.d = pl.nx; q.e = pl.ny; q.f = pl.nz;
-            const Sums6 r = w1_chain_sweep(nd, m, kSweepDist, 1, q, ring);
+            Sums6 r;
+            W1_PH(6, m, r = w1_chain_sweep(nd, m, kSweepDist, 1, q, ring))
             cx.addends += m;
             return r.v[0] / (float)m;
         };
@@ -1771,7 +1846,8 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
             plane_of(count);
             ++iters;
             mp.cx = pl.cx; mp.cy = pl.cy; mp.cz = pl.cz; mp.nx = pl.nx; mp.ny = pl.ny; mp.nz = pl.nz; mp.thr = threshold;
-            const MaskOut mo = w1_mask_pass(nd, kMaskPlane, mp);
+            MaskOut mo;
+            W1_PH(2, n, mo = w1_mask_pass(nd, kMaskPlane, mp))
             const uint32_t newcount = mo.count;
             const bool any_changed = mo.changed != 0, any_differs_prev = mo.differs_prev != 0;
             __syncthreads();
@@ -1925,6 +2001,33 @@ __global__ void debug_eig3_kernel(const float* cov, float* nrm, uint32_t n)
 }
 
 // ------------------------------------------------------------------------------------------
+// micro-benchmark of the two loops patch_fit1 lives in (test hook rpw_debug_loop_bench): every block runs `reps`
+// chain sweeps (what = sweep mode) or mask passes (what = 16 + mask mode) over its own synthetic node of n slots
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kFit1Threads, 4) void w1_loop_bench_kernel(const float* sx, const float* sy, const float* sz, uint8_t* mask,
+                                                                        uint32_t* il, uint32_t n, uint32_t count, int what, int reps, float* out)
+{
+    __shared__ Fit1Shared sh;
+    lds_f32* ring = (lds_f32*)sh.ring;
+    const size_t base = (size_t)blockIdx.x * n;
+    NodeRef nd; nd.x = (g_cf32*)(sx + base); nd.y = (g_cf32*)(sy + base); nd.z = (g_cf32*)(sz + base);
+    nd.m = (g_u8*)(mask + base); nd.il = (g_u32*)(il + base); nd.n = n;
+    float acc = 0.0f;
+    for (int r = 0; r < reps; ++r) {
+        if (what < 16) {
+            SweepPrm prm; prm.a = 0.25f + acc * 0.0f; prm.b = -0.5f; prm.c = 0.125f; prm.d = 0.0f; prm.e = 0.0f; prm.f = 1.0f;
+            const Sums6 v = w1_chain_sweep(nd, count, what, 1, prm, ring);
+            acc += v.v[0];
+        } else {
+            MaskPrm mp; mp.cx = 0.0f; mp.cy = 0.0f; mp.cz = acc * 0.0f; mp.nx = 0.0f; mp.ny = 0.0f; mp.nz = 1.0f; mp.thr = 0.6f;
+            const MaskOut o = w1_mask_pass(nd, what - 16, mp);
+            acc += (float)o.count;
+        }
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
 // host-pointer pipeline helpers: a frame in a pipeline slot is processed by kernels only (no copy-engine
 // operation sits between two frames' kernels): its input is read in place from pinned host memory by bin_tile,
 // and its results are written to pinned host memory by frame_copy_out.
@@ -2004,6 +2107,11 @@ void launch_frame_copy_out(const uint8_t* labels, uint8_t* h_labels, uint32_t n,
     if (blocks < 1) blocks = 1;
     if (blocks > 64) blocks = 64;
     hipLaunchKernelGGL(frame_copy_out_kernel, dim3(blocks), dim3(256), 0, s, labels, h_labels, n, res, h_res, stats, h_stats);
+}
+void launch_loop_bench(const float* sx, const float* sy, const float* sz, uint8_t* mask, uint32_t* il, uint32_t n, uint32_t count,
+                       int what, int reps, uint32_t blocks, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(w1_loop_bench_kernel, dim3(blocks), dim3(kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out);
 }
 void launch_debug_angles(const float* x, const float* y, float* a, uint32_t n, hipStream_t s)
 {

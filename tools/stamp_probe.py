@@ -1,5 +1,6 @@
-"""Diagnostic: per-phase cycles of block 0 (largest patch). Needs RPW_LIB=tools/exp/stamps.so.
-The stamps overwrite the head of the trace buffer, so trace is enabled but emit is disabled (trace=1 with tiny cap)."""
+"""Diagnostic: per-phase cycles of block 0 (the largest patch) of the single-wave patch_fit kernel.
+Needs the diagnostic build:  hipcc ... -DRPW_STAMPS -shared -o tools/exp/stamps.so csrc/rpw_kernels.hip csrc/rpw_capi.hip
+and RPW_LIB=tools/exp/stamps.so. The stamps sit in the last 8 records of the trace buffer (that build returns the whole buffer)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, rpw_amd, ctypes as C
@@ -11,17 +12,15 @@ off = np.array([0, len(frame)], np.uint32); st = torch.cuda.current_stream().cud
 for _ in range(3): eng.segment_batch_device(d.data_ptr(), off, lab.data_ptr(), None, st)
 torch.cuda.synchronize()
 out = np.zeros(4096, rpw_amd.NODE_DTYPE); cnt = C.c_uint32(0)
-import ctypes
-# copy the whole trace buffer (stamps live in its last 8 records)
-eng._L.rpw_set_trace  # noqa
-lib = eng._L
-class H(ctypes.Structure): pass
-st_ = lib.rpw_get_nodes(eng._h, out.ctypes.data, 4096, C.byref(cnt))
-# rpw_get_nodes copies only `count` records; read the tail through a second call with a fake count is not possible,
-# so the probe build reports count = cap (see RPW_STAMPS in rpw_capi.hip)
-raw = out.view(np.uint8)[(4096 - 8) * 68:(4096 - 8) * 68 + 128].view(np.uint64).reshape(2, 8)
-names = ["kernel", "loop", "barrier_wait", "chunks", "passes", "prologue", "epilogue", "n"]
-for w, nm in ((0, "consumer"), (1, "producer")):
-    print(nm, {k: int(v) for k, v in zip(names, raw[w])})
-c = raw[0]
-print("consumer cycles/chunk in loop: %.1f  (barrier wait %.1f);  loop share of kernel %.2f; pro+epi per pass %.0f" % (c[1] / c[3], c[2] / c[3], c[1] / c[0], (c[5] + c[6]) / c[4]))
+eng._L.rpw_get_nodes(eng._h, out.ctypes.data, 4096, C.byref(cnt))
+raw = out.view(np.uint8)[(4096 - 8) * 68:(4096 - 8) * 68 + 128].view(np.uint64)
+names = ["gather", "sweep_range", "mask_pass", "sweep_xyz", "sweep_cov", "eigen", "sweep_dist", "kernel"]
+cyc = {k: int(v) for k, v in zip(names, raw[:8])}
+work = {k: int(v) for k, v in zip(names, raw[8:16])}
+print("seed", os.environ.get("SEED", "0"), "patch points", work["kernel"], "kernel cycles", cyc["kernel"])
+acc = 0
+for k in names[:-1]:
+    per = cyc[k] / max(1, work[k])
+    acc += cyc[k]
+    print(f"  {k:12s} {cyc[k]:10d} cycles ({100.0 * cyc[k] / cyc['kernel']:5.1f} %)  work {work[k]:9d}  -> {per:8.2f} cycles per unit")
+print(f"  other        {cyc['kernel'] - acc:10d} cycles ({100.0 * (cyc['kernel'] - acc) / cyc['kernel']:5.1f} %)")
