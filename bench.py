@@ -4,11 +4,15 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path (classify+bin -> stable scatter -> per-patch recursive plane
-fit -> labels) over one batch of synthetic HDL-64-like frames that is already resident in HBM
-(BASELINE.json configs[1]/[2]: ~127 k points per frame, max_split_depth = 3). Frames are independent,
-so N GPUs run N such batches with no data-path collective ("weak" scaling); the only RCCL call is
-the trivial gather of the per-frame result records.
+A "step" is one pass of the hot path (classify+bin -> per-patch compaction -> recursive plane fit -> labels) over one
+batch of synthetic HDL-64-like frames that is already resident in HBM (BASELINE.json configs[1]/[2]: ~126 k points per
+frame, max_split_depth = 3). Frames are independent, so N GPUs run N such batches with no data-path collective ("weak"
+scaling); the only RCCL call is the gather of every batch's per-frame result record.
+
+`value` is that device-resident throughput. The same JSON line also carries what the DROP-IN path does, host memory in,
+labels in host memory out (`host_path`: the synchronous one-frame call and the rpw_submit / rpw_wait pipeline with 8
+frames in flight = BASELINE.json configs[2]), the latency of one frame, the recursion the workload performs, the two
+rooflines and the CPU baseline.
 
 Prints ONE JSON line on rank 0.
 """
@@ -24,7 +28,7 @@ import numpy as np
 
 # Batches in flight run on separate HIP streams; ROCm multiplexes streams onto 4 hardware queues by
 # default, which would serialise streams that share one. Must be set before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,6 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_POINT_FIT = 17        # 12 sorted xyz + 4 index + 1 label
 BYTES_PER_POINT_BIN = 28        # 12 xyz in + 12 sorted SoA out + 4 index out
+PROFILE_ROUND = "r02"
 
 
 WORKLOADS = {   # name: (generator, config, default frames per step, description) -- BASELINE.json `configs`
@@ -42,6 +47,10 @@ WORKLOADS = {   # name: (generator, config, default frames per step, description
     "c4": ("c4_iac_fused", dict(max_split_depth=1000), 256,
            "c4_iac_fused (configs[3]): 3 fused solid-state sensors, ~296 k points, deep recursion allowed"),
     "c5": ("c5_dense", dict(max_split_depth=6), 64, "c5_dense (configs[4]): dense 1.09 M-point frames"),
+    "rough3": ("rough_terrain", dict(max_split_depth=3, th_dist=0.0005), 256,
+               "rough_terrain: HDL-64-like scan + far-field clutter, th_dist 0.0005: fits split NATURALLY down to depth 3"),
+    "rough6": ("rough_terrain", dict(max_split_depth=6, th_dist=0.0005), 256,
+               "rough_terrain: the same scan, max_split_depth 6: natural splits down to depth 6"),
 }
 
 
@@ -68,64 +77,77 @@ def make_frames(n_frames: int, rank: int, workload: str = "c2"):
     return frames
 
 
-def cpu_baseline(frames, ocfg_kw, budget_s: float = 16.0):
-    """The CPU oracle (a port of the reference algorithm, stdout silent) timed on this box's host
-    cores: single-thread ms/frame and frame-parallel frames/s on all cores (ctypes releases the GIL)."""
-    import oracle_lib as O
-    from concurrent.futures import ThreadPoolExecutor
-    cfg = O.make_config(**ocfg_kw)
-    cores = os.cpu_count() or 1
+def cpu_model() -> str:
     try:
-        cores = len(os.sched_getaffinity(0))
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
     except Exception:
         pass
-    O.segment(frames[0], cfg, want_residual=False, want_nodes=False)      # warm-up
-    # single thread
-    t0 = time.perf_counter(); n1 = 0
-    while time.perf_counter() - t0 < budget_s * 0.4 and n1 < 400:
-        O.segment(frames[n1 % len(frames)], cfg, want_residual=False, want_nodes=False); n1 += 1
-    t1 = time.perf_counter() - t0
-    # all cores, one frame per thread
-    def work(i):
-        O.segment(frames[i % len(frames)], cfg, want_residual=False, want_nodes=False)
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(work, range(cores)))                                   # warm-up
-        t0 = time.perf_counter(); nmt = 0
-        while time.perf_counter() - t0 < budget_s * 0.6:
-            list(ex.map(work, range(nmt, nmt + cores)))
-            nmt += cores
-        tp = time.perf_counter() - t0
+    return "unknown"
+
+
+def cpu_baseline(frames, ocfg_kw, seconds: float = 8.0):
+    """The CPU oracle (a port of the reference algorithm) timed on this box's host cores by its own native harness
+    (oracle/rpw_oracle.cpp rpwo_bench_threads: no Python in the timed loops): single-thread median ms/frame, then
+    one frame per std::thread on all hardware threads. Silent, as the reference is NOT: its as-shipped stdout chatter
+    (about 5 flushed lines per refit iteration, cuda_interface.cu:637-651) is timed separately, into /dev/null."""
+    import oracle_lib as O
+    cfg = O.make_config(**ocfg_kw)
+    sample = frames[: min(len(frames), 64)]
+    r = O.bench_threads(sample, cfg, n_threads=0, seconds=seconds, single_reps=24)
+    # as shipped: the same single-thread run with the reference's prints, stdout -> /dev/null
+    sys.stdout.flush()
+    saved = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    times = []
+    try:
+        os.dup2(devnull, 1)
+        O.set_chatter(True)
+        for i in range(10):
+            t0 = time.perf_counter()
+            O.segment(sample[i % len(sample)], cfg, want_residual=False, want_nodes=False)
+            times.append(time.perf_counter() - t0)
+    finally:
+        O.set_chatter(False)
+        os.dup2(saved, 1)
+        os.close(saved); os.close(devnull)
+    fps = r["frames_done"] / r["elapsed_s"]
     return {
-        "value": round(nmt / tp, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-        "sample": f"{nmt} frames of the bench batch, one frame per thread on {cores} threads "
-                  f"({tp:.1f} s); single thread: {1e3 * t1 / n1:.2f} ms/frame over {n1} frames",
-        "single_thread_ms_per_frame": round(1e3 * t1 / n1, 3),
+        "value": round(fps, 2), "unit": "frames/s", "cores": int(r["threads"]), "kind": "port",
+        "cpu_model": cpu_model(), "hardware_concurrency": int(r["hardware_concurrency"]),
+        "sample": f"{r['frames_done']} frames of the bench batch ({len(sample)} distinct), one frame per std::thread on "
+                  f"{r['threads']} threads, {r['elapsed_s']:.1f} s, native harness; single thread: median of "
+                  f"{r['single_thread_frames']} frames after 3 warm-ups",
+        "single_thread_ms_per_frame": round(r["single_thread_median_ms"], 3),
+        "single_thread_ms_per_frame_as_shipped_chatter_to_devnull": round(1e3 * float(np.median(times)), 3),
     }
 
 
 def load_pmc_traffic(kernel: str, frames_per_launch: int):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
     WRITE_SIZE, separate passes; tools/collect_traffic.sh). Only valid for the batch size it was taken at."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_bench.json")
+    name = f"{PROFILE_ROUND}_pmc_traffic_bench.json"
+    path = os.path.join(ROOT, "profiles", name)
     try:
         d = json.load(open(path))
         if d.get("_meta", {}).get("frames_per_launch", 256) != frames_per_launch:
             return None, None
-        v = d.get(kernel + "_kernel")
-        return (int(v["hbm_bytes_per_launch"]), "profiles/r01_pmc_traffic_bench.json") if v else (None, None)
+        v = d.get(kernel)
+        return (int(v["hbm_bytes_per_launch"]), "profiles/" + name) if v else (None, None)
     except Exception:
         return None, None
 
 
-def gather_counts(local_counts, world):
-    """The path's only collective: all-gather of the per-frame result record (ground-point counts).
-    RCCL on the GPU box (backend "nccl"), gloo in the CPU test."""
+def gather_records(local_rec, world):
+    """The path's only collective: all-gather of the finished batch's per-frame result record (int32 x 4 per frame:
+    ground, non-ground, patches, refits). RCCL on the GPU box (backend "nccl"), gloo in the CPU test."""
     import torch
     import torch.distributed as dist
     if world <= 1:
-        return local_counts.clone()
-    out = torch.empty(local_counts.numel() * world, dtype=local_counts.dtype, device=local_counts.device)
-    dist.all_gather_into_tensor(out, local_counts)
+        return local_rec.clone()
+    out = torch.empty(local_rec.numel() * world, dtype=local_rec.dtype, device=local_rec.device)
+    dist.all_gather_into_tensor(out, local_rec)
     return out
 
 
@@ -139,11 +161,79 @@ def max_over_ranks(elapsed: float, device):
     return float(t.item())
 
 
+def host_path_legs(rpw_amd, cfg_kw, frames, local_rank, seconds=0.8, slots=8):
+    """The drop-in path: frames in host memory in, labels in host memory out (what every caller of the reference does:
+    one std::vector<Point3D> per call). Three ways of driving it, same 8 distinct frames:
+      sync       rpw_segment, one frame at a time
+      in_order   rpw_submit / rpw_wait, `slots` frames in flight, a slot is waited right before it is reused (results
+                 come back in submission order: what a ROS2 node that republishes in order does)
+      any_order  the same slots, refilled as soon as ANY of them has finished (rpw_poll): throughput of a consumer that
+                 does not need the frames in order"""
+    base = frames[: min(8, len(frames))]
+    cap = max(len(f) for f in base)
+    eng = rpw_amd.Engine(rpw_amd.PatchworkConfig(**cfg_kw), device=local_rank, max_points=cap, max_frames=1)
+    out = {"frames": f"{len(base)} distinct frames of the workload, ~{cap} points, pageable host memory in, labels in host memory out",
+           "slots": slots}
+    lab = [np.empty(cap, np.uint8) for _ in range(slots)]
+    for f in base[:3]:
+        eng.segment(f)
+    t0 = time.perf_counter(); k = 0; lat = []
+    while time.perf_counter() - t0 < seconds:
+        t1 = time.perf_counter()
+        eng.segment(base[k % len(base)]); k += 1
+        lat.append(time.perf_counter() - t1)
+    dt = time.perf_counter() - t0
+    out["sync"] = {"frames_per_sec": round(k / dt, 1), "ms_per_frame_median": round(1e3 * float(np.median(lat)), 3),
+                   "ms_per_frame_max": round(1e3 * float(np.max(lat)), 3)}
+    eng.set_pipeline(slots)
+    for s in range(slots):
+        eng.submit(s, base[s % len(base)])
+    for s in range(slots):
+        eng.wait(s, lab[s])
+    # in order
+    pending = [False] * slots; t_sub = [0.0] * slots; lat = []; i = 0; done = 0
+    t0 = time.perf_counter()
+    while True:
+        s = i % slots
+        if pending[s]:
+            eng.wait(s, lab[s]); lat.append(time.perf_counter() - t_sub[s]); done += 1; pending[s] = False
+        if time.perf_counter() - t0 >= seconds:
+            break
+        t_sub[s] = time.perf_counter(); eng.submit(s, base[i % len(base)]); pending[s] = True; i += 1
+    for s in range(slots):
+        if pending[s]:
+            eng.wait(s, lab[s]); done += 1; pending[s] = False
+    dt = time.perf_counter() - t0
+    out["in_order"] = {"frames_per_sec": round(done / dt, 1), "latency_ms_median": round(1e3 * float(np.median(lat)), 3),
+                       "latency_ms_max": round(1e3 * float(np.max(lat)), 3)}
+    # any order
+    lat = []; i = 0; done = 0
+    t0 = time.perf_counter()
+    for s in range(slots):
+        t_sub[s] = time.perf_counter(); eng.submit(s, base[i % len(base)]); pending[s] = True; i += 1
+    stop = False
+    while any(pending):
+        progressed = False
+        for s in range(slots):
+            if pending[s] and eng.poll(s):
+                eng.wait(s, lab[s]); lat.append(time.perf_counter() - t_sub[s]); done += 1; pending[s] = False; progressed = True
+                stop = stop or (time.perf_counter() - t0 >= seconds)
+                if not stop:
+                    t_sub[s] = time.perf_counter(); eng.submit(s, base[i % len(base)]); pending[s] = True; i += 1
+        if not progressed:
+            time.sleep(0)                                    # yield; the polls themselves are cheap event queries
+    dt = time.perf_counter() - t0
+    out["any_order"] = {"frames_per_sec": round(done / dt, 1), "latency_ms_median": round(1e3 * float(np.median(lat)), 3),
+                        "latency_ms_max": round(1e3 * float(np.max(lat)), 3)}
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=18)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=126, help="timed steps (default: about one second)")
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 (default) is the configuration the metric is quoted on; the others are informational")
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (one batch); 0 = the workload's default (c2: 512)")
@@ -151,12 +241,11 @@ def main():
     ap.add_argument("--max-iter", type=int, default=100,
                     help="refit iterations; 0 = SURVEY.md 8d 'variant B' (every fit ends at once, so the recursion is forced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--single-frame-latency", action="store_true",
-                    help="also time batches of ONE frame (extra launches of the same kernels; off by default so that "
-                         "rocprofv3 --stats averages describe the bench batch only)")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-path legs and the single-frame latency "
+                    "(extra launches of the same kernels: leave them out when rocprofv3 --stats averages should describe the bench batch only)")
     ap.add_argument("--no-profile-events", action="store_true")
     ap.add_argument("--end-to-end", action="store_true",
-                    help="also time the PCIe-inclusive pipeline (pinned host xyz in, labels back to pinned host memory, "
+                    help="also time the PCIe-inclusive BATCH pipeline (pinned host xyz in, labels back to pinned host memory, "
                          "copies and kernels of consecutive batches overlapped on the streams); reported beside `value`, never as it")
     args = ap.parse_args()
 
@@ -165,13 +254,14 @@ def main():
     import rpw_amd
 
     if not os.path.exists(rpw_amd.LIB_PATH):          # a snapshot without built artefacts: compile in-tree first
+        done_file = rpw_amd.LIB_PATH + ".built"
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
             rpw_amd.build()
-        else:                                         # the other ranks of the node wait for local rank 0's build
+            open(done_file, "w").write("ok")
+        else:                                         # the other ranks of the node wait for local rank 0's finished build
             t_wait = time.time()
-            while not os.path.exists(rpw_amd.LIB_PATH) and time.time() - t_wait < 600:
-                time.sleep(1.0)
-            time.sleep(2.0)
+            while not os.path.exists(done_file) and time.time() - t_wait < 900:
+                time.sleep(0.5)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -209,8 +299,11 @@ def main():
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
     stream = streams[0]
     F = len(frames)
-    gather_in = torch.zeros(F, dtype=torch.int32, device=dev)
+    # result gather (world > 1): every step's per-frame record {ground, non-ground, patches, refits} is written on the
+    # device behind the batch (event dependency on the batch's stream) and all-gathered over RCCL on a stream of its own
+    rec = [torch.zeros(4 * F, dtype=torch.int32, device=dev) for _ in range(n_streams)]
     gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    gathered = [None]
     step_no = [0]
 
     def step():
@@ -219,10 +312,10 @@ def main():
         engines[k].segment_batch_device(d_xyz.data_ptr(), offsets, d_labels_all[k].data_ptr(), None,
                                         streams[k].cuda_stream)
         if world > 1:
-            # trivial result gather: ground-point count per frame (RCCL all-gather of F int32 per rank), on a stream
-            # of its own: issued on a batch's stream it would make that stream's next batch wait for the collective
+            # on its own stream: issued on the batch's stream the collective would hold back that stream's next batch
+            engines[k].result_record_device(rec[k].data_ptr(), F, gather_stream.cuda_stream)    # waits for THIS batch (event)
             with torch.cuda.stream(gather_stream):
-                gather_counts(gather_in, world)
+                gathered[0] = gather_records(rec[k], world)
 
     # set-up, not a step: every engine (one per stream) runs once so that its first-call costs (lazy buffers, code
     # object load) are paid before the W warm-up steps, whatever W is
@@ -241,7 +334,6 @@ def main():
         lab0 = d_labels[: len(frames[0])].cpu().numpy()
         if not np.array_equal(lab0, ref.labels):
             raise SystemExit("bench: HIP labels differ from the oracle on frame 0 -- refusing to report")
-    gather_in.copy_(torch.from_numpy(st["n_ground"].astype(np.int32)))
     chain_addends_per_batch = int(st["chain_addends"].astype(np.int64).sum())
 
     step_no[0] = 0
@@ -260,8 +352,15 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, dev)
+    gather_check = None
+    if world > 1 and rank == 0:
+        g = gathered[0].cpu().numpy().reshape(world, F, 4)
+        mine = np.stack([st["n_ground"], st["n_zone"] - st["n_ground"], st["n_patches"], st["total_iterations"]], axis=1).astype(np.int32)
+        gather_check = {"own_block_equals_stats": bool(np.array_equal(g[0], mine)),
+                        "ranks_with_ground_points": int((g[:, :, 0].sum(axis=1) > 0).sum())}
     kms = None
     kms_solo = None
+    gather_ms = None
     if not args.no_profile_events:
         kms = {}
         for e in engines:
@@ -277,23 +376,43 @@ def main():
             eng.segment_batch_device(d_xyz.data_ptr(), offsets, d_labels.data_ptr(), None, stream.cuda_stream)
         torch.cuda.synchronize()
         kms_solo = eng.kernel_ms(reset=True)
-        eng.set_profiling(False)
-
-    # single-frame latency (batch of 1), informational
-    lat_ms = None
-    if rank == 0 and args.single_frame_latency:
-        off1 = offsets[:2].copy()
+        # ... and the per-patch compaction that completes the binning pass (patch_fit's gather prologue), by a
+        # diagnostic launch that stops behind it
+        eng.set_debug_gather_only(True)
         for _ in range(3):
-            eng.segment_batch_device(d_xyz.data_ptr(), off1, d_labels.data_ptr(), None, stream.cuda_stream)
+            eng.segment_batch_device(d_xyz.data_ptr(), offsets, d_labels.data_ptr(), None, stream.cuda_stream)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        reps = 20
-        for _ in range(reps):
-            eng.segment_batch_device(d_xyz.data_ptr(), off1, d_labels.data_ptr(), None, stream.cuda_stream)
-            torch.cuda.synchronize()
-        lat_ms = 1e3 * (time.perf_counter() - t1) / reps
+        g = eng.kernel_ms(reset=True)
+        gather_ms = g["patch_fit"][0] / max(1, g["patch_fit"][1])
+        eng.set_debug_gather_only(False)
+        eng.set_profiling(False)
+        eng.segment_batch_device(d_xyz.data_ptr(), offsets, d_labels.data_ptr(), None, stream.cuda_stream)   # labels valid again
+        torch.cuda.synchronize()
 
-    # PCIe-inclusive pipeline, informational (SURVEY.md 8d "end-to-end"): every batch is copied in from pinned host
+    # latency of ONE frame, device-resident (batch of 1), over the 8 distinct frames
+    lat = None
+    host_path = None
+    if rank == 0 and not args.no_host_path:
+        one = rpw_amd.Engine(rpw_amd.PatchworkConfig(**cfg_kw), device=local_rank, max_points=max(len(f) for f in frames[:8]), max_frames=1)
+        lat_ms = []
+        for fi in range(min(8, F)):
+            off1 = np.array([0, len(frames[fi])], np.uint32)
+            src = d_xyz[int(offsets[fi]): int(offsets[fi + 1])]
+            for rep in range(4):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                one.segment_batch_device(src.data_ptr(), off1, d_labels.data_ptr(), None, stream.cuda_stream)
+                torch.cuda.synchronize()
+                if rep:
+                    lat_ms.append(1e3 * (time.perf_counter() - t1))
+        one.close()
+        lat = {"median": round(float(np.median(lat_ms)), 4), "min": round(float(np.min(lat_ms)), 4), "max": round(float(np.max(lat_ms)), 4),
+               "what": "one frame per launch, device-resident, 8 distinct frames x 3 runs"}
+        eng.segment_batch_device(d_xyz.data_ptr(), offsets, d_labels.data_ptr(), None, stream.cuda_stream)
+        torch.cuda.synchronize()
+        host_path = host_path_legs(rpw_amd, cfg_kw, frames, local_rank)
+
+    # PCIe-inclusive BATCH pipeline, informational (SURVEY.md 8d "end-to-end"): every batch is copied in from pinned host
     # memory and its labels are copied back, on the batch's own stream, so copies overlap other batches' kernels
     e2e = None
     if world == 1 and args.end_to_end:
@@ -312,13 +431,14 @@ def main():
             e2e_step(i)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(args.steps):
+        n_e2e = min(args.steps, 36)
+        for i in range(n_e2e):
             e2e_step(i)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         same = bool(torch.equal(h_lab[0], d_labels_all[0].cpu()))
-        e2e = {"frames_per_sec": round(F * args.steps / dt, 2), "ms_per_step": round(1e3 * dt / args.steps, 4),
-               "host_GBps": round((12 + 1) * total_pts * args.steps / dt / 1e9, 2), "labels_match_device_run": same,
+        e2e = {"frames_per_sec": round(F * n_e2e / dt, 2), "ms_per_step": round(1e3 * dt / n_e2e, 4),
+               "host_GBps": round((12 + 1) * total_pts * n_e2e / dt / 1e9, 2), "labels_match_device_run": same,
                "includes": "H2D of the xyz batch + D2H of the labels over PCIe from/to pinned host memory, per batch, on its stream"}
 
     if rank == 0:
@@ -335,10 +455,24 @@ def main():
                 "frames_per_gpu_per_step": F, "batches_in_flight_per_gpu": n_streams,
                 "points_per_frame": int(total_pts // F),
                 "max_split_depth": cfg_kw.get("max_split_depth", 1000), "max_iter": cfg_kw.get("max_iter", 100), "num_sectors": 10,
+                "th_dist": cfg_kw.get("th_dist", 0.2),
             },
+            "api": {"value": "rpw_segment_batch_device (device pointers, whole batches)",
+                    "host_path": "rpw_segment (sync) and rpw_submit / rpw_wait (pipeline): host pointers, one frame per call"},
             "ms_per_frame": round(1e3 * elapsed / (F * args.steps), 5),
-            "single_frame_latency_ms": None if lat_ms is None else round(lat_ms, 4),
+            "timed_region_s": round(elapsed, 3),
+            # what the recursion did on this workload (a zero here means the headline batch never splits)
+            "recursion": {"n_splits_per_frame_mean": round(float(st["n_splits"].mean()), 3),
+                          "frames_with_splits": int((st["n_splits"] > 0).sum()),
+                          "max_depth_reached": int(st["max_depth"].max()),
+                          "nodes_per_frame_mean": round(float(st["n_nodes"].mean()), 2),
+                          "refits_per_frame_mean": round(float(st["total_iterations"].mean()), 1)},
+            "single_frame_latency_ms": None if lat is None else lat["median"],
+            "single_frame_latency": lat,
+            "host_path": host_path,
         }
+        if gather_check is not None:
+            out["result_gather"] = gather_check
         if e2e is not None:
             out["end_to_end"] = e2e
         if kms is not None:
@@ -349,16 +483,18 @@ def main():
             avg_s = (kms[dom][0] / max(1, kms[dom][1])) * 1e-3
             bpp = BYTES_PER_POINT_FIT if dom == "patch_fit" else BYTES_PER_POINT_BIN
             ach = bpp * total_pts / avg_s / 1e9
-            traffic, traffic_src = load_pmc_traffic(dom, F)
+            kname = {"patch_fit": "patch_fit1_kernel", "bin_tile": "bin_tile_kernel", "scan_offsets": "scan_offsets_kernel"}[dom]
+            traffic, traffic_src = load_pmc_traffic(kname, F)
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "traffic_source": traffic_src, "algorithmic_bytes_per_point": bpp,
                                "algorithmic_bytes_per_launch": bpp * total_pts,
+                               "launches_in_flight": n_streams,
                                "note": "patch_fit is bound by sequential binary32 add chains (8.2 cycles per dependent "
-                                       "v_add_f32), not by HBM; see DESIGN.md section 4"}
-            # the bound that actually governs patch_fit: sequential binary32 adds. A dependent v_add_f32 retires every
-            # 3.4 ns (8.2 cycles, tools/microbench_chain.hip); a SIMD sustains two such chains at full rate, so the chip
-            # tops out at 256 CUs x 8 chains / 3.4 ns, whatever the lanes beside the chain lanes do.
+                                       "v_add_f32) and by instruction issue, not by HBM; see DESIGN.md section 4. The duration "
+                                       "is the average launch in the timed region, where launches_in_flight launches share the chip."}
+            # the bound that governs patch_fit: sequential binary32 adds. A dependent v_add_f32 retires every
+            # 3.4 ns (8.2 cycles, tools/microbench_chain.hip); the chip tops out at 256 CUs x 8 chains / 3.4 ns.
             chain_peak = 256 * 8 / 3.4e-9
             chain_rate = chain_addends_per_batch * world * args.steps / elapsed
             out["chain_roofline"] = {"kernel": "patch_fit", "bound": "dependent fp32 add latency",
@@ -366,20 +502,32 @@ def main():
                                      "unit": "G sequential addends/s (per accumulator row)",
                                      "frac": round(chain_rate / chain_peak, 4),
                                      "addends_per_frame": chain_addends_per_batch // F}
-            bin_s = sum(kms_solo[k][0] / max(1, kms_solo[k][1]) for k in ("bin_tile", "scan_offsets")) * 1e-3
+            solo = {k: kms_solo[k][0] / max(1, kms_solo[k][1]) for k in kms_solo}
+            bin_s = (solo["bin_tile"] + solo["scan_offsets"]) * 1e-3
             achb = BYTES_PER_POINT_BIN * total_pts / bin_s / 1e9
-            tb1, tsrc1 = load_pmc_traffic("bin_tile", F)
-            tb2, _ = load_pmc_traffic("scan_offsets", F)
+            tb1, tsrc1 = load_pmc_traffic("bin_tile_kernel", F)
+            tb2, _ = load_pmc_traffic("scan_offsets_kernel", F)
+            full_s = bin_s + gather_ms * 1e-3
             out["roofline_binning"] = {"kernels": "bin_tile+scan_offsets", "bound": "hbm",
                                        "measured": "one stream, right after the timed region (in it these kernels queue "
-                                                   "behind other streams' patch_fit waves)",
+                                                   "behind other streams' patch_fit waves: see in_timed_region_ms)",
                                        "ms_per_launch": round(bin_s * 1e3, 4),
+                                       "in_timed_region_ms": round(per["bin_tile"] + per["scan_offsets"], 4),
                                        "achieved": round(achb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(achb / HBM_PEAK_GBS, 5),
                                        "traffic": None if tb1 is None or tb2 is None else tb1 + tb2,
                                        "traffic_source": tsrc1,
                                        "algorithmic_bytes_per_point": BYTES_PER_POINT_BIN,
-                                       "algorithmic_bytes_per_launch": BYTES_PER_POINT_BIN * total_pts}
+                                       "algorithmic_bytes_per_launch": BYTES_PER_POINT_BIN * total_pts,
+                                       # the WHOLE binning pass of north_star: + the per-patch compaction (patch_fit's gather prologue)
+                                       "with_per_patch_compaction": {
+                                           "kernels": "bin_tile+scan_offsets+patch_fit(gather prologue only, diagnostic launch)",
+                                           "gather_ms_per_launch": round(gather_ms, 4),
+                                           "ms_per_launch": round(full_s * 1e3, 4),
+                                           "achieved": round(BYTES_PER_POINT_BIN * total_pts / full_s / 1e9, 2),
+                                           "frac": round(BYTES_PER_POINT_BIN * total_pts / full_s / 1e9 / HBM_PEAK_GBS, 5),
+                                           "actual_bytes_per_point": "12 read + 16 written (tile-sorted records) + 16 read + 16 written (patch-sorted SoA + index)",
+                                           "frac_of_actual_bytes": round(60 * total_pts / full_s / 1e9 / HBM_PEAK_GBS, 5)}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, cfg_kw)
         print(json.dumps(out), flush=True)

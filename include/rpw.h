@@ -220,6 +220,12 @@ rpw_status  rpw_segment_batch_device(rpw_handle* h, const float* d_xyz, const ui
 /* Waits for the last batch and copies its per-frame stats (n_frames records) to the host. */
 rpw_status  rpw_get_batch_stats(rpw_handle* h, rpw_frame_stats* stats, uint32_t n_frames);
 
+/* Per-frame result record of the last batch, written on the DEVICE as four int32 per frame -- ground points, non-ground
+ * points of the zone, patches, refits (the counts a reference caller sees, recursive_patchwork.cpp:421-423) -- into d_out
+ * (device memory, 4 * n_frames int32). Enqueued on `stream` behind the batch (an event dependency if `stream` is not the
+ * batch's own): what the multi-GPU result gather sends, with no host round trip. */
+rpw_status  rpw_result_record_device(rpw_handle* h, int32_t* d_out, uint32_t n_frames, void* stream);
+
 /* Optional recursion-tree trace of the last call (costs a little time; off by default). */
 rpw_status  rpw_set_trace(rpw_handle* h, int enable, uint32_t max_nodes);
 rpw_status  rpw_get_nodes(rpw_handle* h, rpw_node* nodes, uint32_t cap, uint32_t* n_nodes);
@@ -232,6 +238,9 @@ rpw_status  rpw_get_kernel_ms(rpw_handle* h, double ms[RPW_K_COUNT], uint64_t la
  * evaluated on the DEVICE over arrays held in host memory. */
 rpw_status  rpw_debug_angles(rpw_handle* h, const float* x, const float* y, float* angle, uint32_t n);
 rpw_status  rpw_debug_eig3(rpw_handle* h, const float* cov9, float* normal3, uint32_t n);
+/* Diagnostic: with enable != 0 the plane-fit kernel stops behind its gather prologue (the per-patch compaction that
+ * completes the binning pass), so that pass can be timed on its own. Labels are not produced in that mode. */
+rpw_status  rpw_set_debug_gather_only(rpw_handle* h, int enable);
 /* Micro-benchmark of the two loops the plane-fit kernel lives in, on a synthetic node of n slots of which inlier_pct %
  * are inliers, one node per workgroup, `blocks` workgroups, `reps` passes each: what = 0..5 chain sweeps (centroid,
  * covariance, residual, range, xy, variance), 16..18 mask passes (seed, plane, older). ms = device time of the launch. */

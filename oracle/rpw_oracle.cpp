@@ -27,17 +27,30 @@
 #include "rpw_oracle.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <iostream>
 #include <limits>
 #include <numeric>
+#include <random>
+#include <thread>
 #include <vector>
 
 namespace {
 
 // optional per-iteration trace (analysis aid): {patch, depth, iter, count, hash} as 5 x uint64
 uint64_t* g_iter_trace = nullptr; uint32_t g_iter_cap = 0, g_iter_n = 0;
+
+// "As shipped" mode (rpwo_set_chatter): print what a CUDA-less build of the reference prints on its way through the
+// path, line for line and flushed with std::endl like there -- cuda_interface.cu:57 (isAvailable, once per cuda::ops
+// call), :586,592 (computeDistances2D), :603,611-612 (filterPointsByRadius), :621,629 (computeAngles), :637,642,643,651
+// (computePlaneDistances: once per refit iteration per patch), recursive_patchwork.cpp:30-31,421-423. Off by default:
+// the checker and the headline CPU baseline run silent.
+int g_chatter = 0;
+inline void say_unavailable() { if (g_chatter) std::cout << "USE_CUDA not defined, CUDA not available" << std::endl; }
 
 struct P3 { float x, y, z; };
 
@@ -361,8 +374,15 @@ std::vector<bool> fit_plane_and_split(Ctx& cx, const std::vector<P3>& pts, float
         const Plane pl = fit_plane_pca(inl);
         ++iterations;
         std::vector<bool> next(n, false);
+        if (g_chatter) {                        // cuda::ops::computePlaneDistances, CPU branch (cuda_interface.cu:634-654)
+            std::cout << "computePlaneDistances called with " << n << " points" << std::endl;
+            say_unavailable();
+            std::cout << "Using CPU for plane distances" << std::endl;
+            std::cout << "[CPU] Computing plane distances for " << n << " points..." << std::endl;
+        }
         for (size_t i = 0; i < n; ++i)
             if (plane_distance(pts[i], pl.c, pl.n) < threshold) next[i] = true;
+        if (g_chatter) std::cout << "[CPU] Plane distance computation completed successfully" << std::endl;
         if (g_iter_trace && g_iter_n < g_iter_cap) {
             uint64_t h = 1469598103934665603ull, cnt = 0;
             for (size_t i = 0; i < n; ++i) if (next[i]) { h = (h ^ (uint64_t)i) * 1099511628211ull; ++cnt; }
@@ -529,12 +549,21 @@ int rpwo_segment(const rpwo_config* cfg, const float* xyz, uint32_t n, uint8_t* 
         }
     }
     st->n_clean = (uint32_t)cleaned.size();
+    const auto t_start = std::chrono::high_resolution_clock::now();
+    if (g_chatter && cleaned.size() < n)
+        std::cout << "Removed " << (n - cleaned.size()) << " points with NaN/inf values" << std::endl;
     if (cleaned.empty()) return 0;
 
     // computeDistances2D (cuda_interface.cu:582-595), filterPointsByRadius (:597-615), RP.cpp:328-334
+    if (g_chatter) { say_unavailable(); std::cout << "[CPU] Computing 2D distances for " << cleaned.size() << " points..." << std::endl; }
     std::vector<float> dist(cleaned.size());
     for (size_t i = 0; i < cleaned.size(); ++i)
         dist[i] = std::sqrt(cleaned[i].x * cleaned[i].x + cleaned[i].y * cleaned[i].y);
+    if (g_chatter) {
+        std::cout << "[CPU] 2D distance computation completed successfully" << std::endl;
+        say_unavailable();
+        std::cout << "[CPU] Filtering " << cleaned.size() << " points by radius " << cfg->filtering_radius << "..." << std::endl;
+    }
     std::vector<P3> zone; std::vector<float> d_zone; std::vector<uint32_t> zone_src;
     zone.reserve(cleaned.size()); d_zone.reserve(cleaned.size()); zone_src.reserve(cleaned.size());
     for (size_t i = 0; i < cleaned.size(); ++i) {
@@ -545,6 +574,8 @@ int rpwo_segment(const rpwo_config* cfg, const float* xyz, uint32_t n, uint8_t* 
         }
     }
     st->n_zone = (uint32_t)zone.size();
+    if (g_chatter)
+        std::cout << "[CPU] Point filtering completed successfully. Filtered: " << zone.size() << "/" << cleaned.size() << " points" << std::endl;
     if (zone.size() < 3) return 0;   // RP.cpp:339-341: everything cleaned is non-ground
 
     float edges[9];
@@ -552,8 +583,10 @@ int rpwo_segment(const rpwo_config* cfg, const float* xyz, uint32_t n, uint8_t* 
     make_tables(*cfg, edges, bounds);
     const int num_rings = 8;
 
+    if (g_chatter) { say_unavailable(); std::cout << "[CPU] Computing angles for " << zone.size() << " points..." << std::endl; }
     std::vector<float> angles(zone.size());
     for (size_t i = 0; i < zone.size(); ++i) angles[i] = angle_of(zone[i].x, zone[i].y);
+    if (g_chatter) std::cout << "[CPU] Angle computation completed successfully" << std::endl;
 
     std::vector<bool> is_ground(zone.size(), false);
     std::vector<P3> patch_pts;
@@ -600,6 +633,11 @@ int rpwo_segment(const rpwo_config* cfg, const float* xyz, uint32_t n, uint8_t* 
     for (size_t i = 0; i < zone.size(); ++i)
         if (is_ground[i]) { labels[zone_src[i]] = RPWO_GROUND; ++ng; }
     st->n_ground = ng;
+    if (g_chatter) {                             // RP.cpp:421-423
+        const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t_start).count();
+        std::cout << "Ground filtering completed in " << secs << " seconds" << std::endl;
+        std::cout << "Ground points: " << ng << ", Non-ground points: " << (cleaned.size() - ng) << std::endl;
+    }
     return 0;
 }
 
@@ -626,6 +664,99 @@ int rpwo_filter_ground_points(const rpwo_config* cfg, const float* xyz, uint32_t
     }
     for (uint32_t i = 0; i < n; ++i) if (labels[i] == RPWO_OUTSIDE) push(nonground_xyz, ng, i);
     *n_ground = g; *n_nonground = ng;
+    return 0;
+}
+
+void rpwo_set_chatter(int on) { g_chatter = on ? 1 : 0; }
+
+// sampleGroundAndObstacles (RP.cpp:428-465) with PointCloudProcessor::randomSubsample (PCP.cpp:121-146) restated.
+// The reference seeds std::mt19937 from std::random_device; here the seed is an argument, everything else is the same:
+// uniform_int_distribution<size_t>(0, size - 1) draws, rejection of repeats, points appended in draw order.
+int rpwo_sample_ground_and_obstacles(const rpwo_config* cfg, const float* xyz, uint32_t n, float target_height,
+                                     float base_tol, uint32_t seed, float* out_xyz, uint32_t* n_out)
+{
+    std::vector<float> g((size_t)n * 3 + 3), ng((size_t)n * 3 + 3);
+    uint32_t cg = 0, cn = 0;
+    int rc = rpwo_filter_ground_points(cfg, xyz, n, g.data(), &cg, ng.data(), &cn);
+    if (rc) return rc;
+    uint32_t k = 0;
+    auto push = [&](const float* p) { out_xyz[3 * k] = p[0]; out_xyz[3 * k + 1] = p[1]; out_xyz[3 * k + 2] = p[2]; ++k; };
+    if (cn == 0) {                                                     // RP.cpp:434-436: return ground_points
+        for (uint32_t i = 0; i < cg; ++i) push(&g[3 * (size_t)i]);
+        *n_out = k; return 0;
+    }
+    // ground sample first (RP.cpp:451-462), then the obstacle points
+    if (cg > 0) {
+        const size_t target = std::min<size_t>(2000, cg);
+        if (cg <= target) {
+            for (uint32_t i = 0; i < cg; ++i) push(&g[3 * (size_t)i]);
+        } else {
+            std::mt19937 gen(seed);
+            std::uniform_int_distribution<size_t> dis(0, (size_t)cg - 1);
+            std::vector<bool> selected(cg, false);
+            size_t count = 0;
+            while (count < target) {
+                const size_t idx = dis(gen);
+                if (!selected[idx]) { selected[idx] = true; push(&g[3 * idx]); ++count; }
+            }
+        }
+    }
+    for (uint32_t i = 0; i < cn; ++i) {
+        const float* p = &ng[3 * (size_t)i];
+        if (!(std::sqrt(p[0] * p[0] + p[1] * p[1]) > 2.5f)) continue;    // removeEgoVehicle(non_ground, 2.5f), RP.cpp:64-75
+        if (std::abs(p[2] - target_height) <= base_tol) push(p);         // RP.cpp:445-449
+    }
+    *n_out = k;
+    return 0;
+}
+
+// CPU baseline harness: no Python in the loop. Phase 1: one thread, every frame once after warm-ups, per-frame times
+// (median reported). Phase 2: n_threads std::threads, thread t segments frames t, t + n_threads, ... round and round
+// until `seconds` have passed; frames finished / wall time = frames per second on n_threads threads.
+int rpwo_bench_threads(const rpwo_config* cfg, const float* xyz, const uint32_t* frame_off, uint32_t n_frames,
+                       uint32_t n_threads, double seconds, uint32_t single_reps, rpwo_bench_result* out)
+{
+    if (!cfg || !xyz || !frame_off || !out || n_frames == 0) return 1;
+    if (n_threads == 0) n_threads = std::thread::hardware_concurrency();
+    if (n_threads == 0) n_threads = 1;
+    auto run = [&](uint32_t f, std::vector<uint8_t>& lab) {
+        const uint32_t nf = frame_off[f + 1] - frame_off[f];
+        if (lab.size() < nf) lab.resize(nf);
+        rpwo_stats st;
+        (void)rpwo_segment(cfg, xyz + 3 * (size_t)frame_off[f], nf, lab.data(), nullptr, nullptr, 0, &st);
+    };
+    using clk = std::chrono::steady_clock;
+    std::vector<uint8_t> lab;
+    for (uint32_t w = 0; w < 3 && w < n_frames; ++w) run(w, lab);          // warm-ups
+    std::vector<double> t;
+    const uint32_t reps = single_reps ? single_reps : 20;
+    for (uint32_t r = 0; r < reps; ++r) {
+        const auto a = clk::now();
+        run(r % n_frames, lab);
+        t.push_back(std::chrono::duration<double, std::milli>(clk::now() - a).count());
+    }
+    std::sort(t.begin(), t.end());
+    out->single_thread_median_ms = t[t.size() / 2];
+    out->single_thread_frames = (uint32_t)t.size();
+    out->hardware_concurrency = std::thread::hardware_concurrency();
+    out->threads = n_threads;
+    std::atomic<uint64_t> done{0};
+    std::atomic<int> stop{0};
+    std::vector<std::thread> th;
+    const auto t0 = clk::now();
+    for (uint32_t k = 0; k < n_threads; ++k)
+        th.emplace_back([&, k]() {
+            std::vector<uint8_t> l;
+            for (uint32_t f = k % n_frames; !stop.load(std::memory_order_relaxed); f = (f + n_threads) % n_frames) {
+                run(f, l);
+                done.fetch_add(1, std::memory_order_relaxed);
+            }
+        });
+    while (std::chrono::duration<double>(clk::now() - t0).count() < seconds) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    stop.store(1);
+    for (auto& x : th) x.join();                                             // (frames in progress at the bell are finished and counted)
+    out->elapsed_s = std::chrono::duration<double>(clk::now() - t0).count();
+    out->frames_done = done.load();
     return 0;
 }
 

@@ -103,6 +103,28 @@ int rpwo_filter_ground_points(const rpwo_config* cfg, const float* xyz, uint32_t
 int rpwo_fuse(const float* xyz, const uint32_t* sensor_off, uint32_t n_sensors, const float* rotation_deg,
               const float* ego_radius, float* out_xyz, uint32_t* out_src, uint32_t* n_out);
 
+/* sampleGroundAndObstacles (reference src/recursive_patchwork.cpp:428-465, randomSubsample src/point_cloud_processor.cpp:121-146)
+ * with the std::mt19937 seed as an argument (the reference seeds from std::random_device). out_xyz must hold n points. */
+int rpwo_sample_ground_and_obstacles(const rpwo_config* cfg, const float* xyz, uint32_t n, float target_height,
+                                     float base_tol, uint32_t seed, float* out_xyz, uint32_t* n_out);
+
+/* "as shipped" mode: print, flushed, the lines a CUDA-less build of the reference prints on the path
+ * (cuda_interface.cu:57,586-651; recursive_patchwork.cpp:30,421-423). Process-wide; off by default. */
+void rpwo_set_chatter(int on);
+
+/* CPU baseline harness (bench.py cpu_baseline): native threads, one frame per thread at a time. frames are
+ * concatenated in xyz, frame f = points [frame_off[f], frame_off[f+1]). n_threads = 0: hardware_concurrency. */
+typedef struct rpwo_bench_result {
+    double   single_thread_median_ms;   /* median over single_thread_frames frames, after 3 warm-ups */
+    uint32_t single_thread_frames;
+    uint32_t threads;                   /* threads of the parallel phase                              */
+    uint32_t hardware_concurrency;      /* std::thread::hardware_concurrency()                        */
+    uint64_t frames_done;               /* parallel phase                                             */
+    double   elapsed_s;
+} rpwo_bench_result;
+int rpwo_bench_threads(const rpwo_config* cfg, const float* xyz, const uint32_t* frame_off, uint32_t n_frames,
+                       uint32_t n_threads, double seconds, uint32_t single_reps, rpwo_bench_result* out);
+
 /* analysis aid: record {patch, depth, iter, inlier count, mask hash} (5 x uint64) for every loop
  * iteration of the following rpwo_segment calls; buf = NULL switches it off */
 void     rpwo_set_iter_trace(uint64_t* buf, uint32_t cap);

@@ -147,6 +147,10 @@ def load_library():
     L.rpw_segment_batch_device.restype = i32
     L.rpw_get_batch_stats.argtypes = [vp, vp, u32]
     L.rpw_get_batch_stats.restype = i32
+    L.rpw_result_record_device.argtypes = [vp, vp, u32, vp]
+    L.rpw_result_record_device.restype = i32
+    L.rpw_set_debug_gather_only.argtypes = [vp, i32]
+    L.rpw_set_debug_gather_only.restype = i32
     L.rpw_set_trace.argtypes = [vp, i32, u32]
     L.rpw_set_trace.restype = i32
     L.rpw_get_nodes.argtypes = [vp, vp, u32, C.POINTER(u32)]
@@ -173,7 +177,7 @@ EXPORTED_SYMBOLS = (
     "rpw_submit", "rpw_submit_pointcloud2", "rpw_poll", "rpw_wait", "rpw_set_sensors", "rpw_segment_fused",
     "rpw_segment_batch_device_fused", "rpw_segment_batch_device", "rpw_get_batch_stats", "rpw_set_trace",
     "rpw_get_nodes", "rpw_set_profiling", "rpw_get_kernel_ms", "rpw_debug_angles", "rpw_debug_eig3",
-    "rpw_debug_angles_host", "rpw_debug_loop_bench",
+    "rpw_debug_angles_host", "rpw_debug_loop_bench", "rpw_result_record_device", "rpw_set_debug_gather_only",
 )
 
 
@@ -323,6 +327,13 @@ class Engine:
         off = np.ascontiguousarray(frame_offsets, dtype=np.uint32)
         self._check(self._L.rpw_segment_batch_device(self._h, d_xyz_ptr, off.ctypes.data, len(off) - 1,
                                                      d_labels_ptr, d_residual_ptr or None, stream or None))
+
+    def result_record_device(self, d_out_ptr: int, n_frames: int, stream: int | None = None):
+        """int32[4 * n_frames] {ground, non-ground in zone, patches, refits} per frame of the last batch, written on the device."""
+        self._check(self._L.rpw_result_record_device(self._h, d_out_ptr, n_frames, stream or None))
+
+    def set_debug_gather_only(self, enable: bool):
+        self._check(self._L.rpw_set_debug_gather_only(self._h, int(enable)))
 
     def batch_stats(self, n_frames: int) -> np.ndarray:
         out = np.zeros(n_frames, STATS_DTYPE)

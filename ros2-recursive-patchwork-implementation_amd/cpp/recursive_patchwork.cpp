@@ -40,9 +40,39 @@ RecursivePatchwork::~RecursivePatchwork()
     if (handle_) rpw_destroy(handle_);
 }
 
+RecursivePatchwork::RecursivePatchwork(const RecursivePatchwork& o)
+    : config_(o.config_), device_(o.device_), sample_seed_(o.sample_seed_), have_sample_seed_(o.have_sample_seed_)
+{
+    ensure(o.capacity_ ? o.capacity_ : (1u << 18));
+    setPipelineDepth(o.depth_);
+}
+
+RecursivePatchwork& RecursivePatchwork::operator=(const RecursivePatchwork& o)
+{
+    if (this == &o) return *this;
+    RecursivePatchwork tmp(o);
+    *this = std::move(tmp);
+    return *this;
+}
+
+RecursivePatchwork::RecursivePatchwork(RecursivePatchwork&& o) noexcept { *this = std::move(o); }
+
+RecursivePatchwork& RecursivePatchwork::operator=(RecursivePatchwork&& o) noexcept
+{
+    if (this == &o) return *this;
+    if (handle_) rpw_destroy(handle_);
+    config_ = o.config_; handle_ = o.handle_; capacity_ = o.capacity_; device_ = o.device_; n_zone_last_ = o.n_zone_last_;
+    sample_seed_ = o.sample_seed_; have_sample_seed_ = o.have_sample_seed_; depth_ = o.depth_; slots_ = std::move(o.slots_);
+    o.handle_ = nullptr; o.capacity_ = 0; o.depth_ = 0; o.slots_.clear();
+    return *this;
+}
+
 void RecursivePatchwork::ensure(size_t n)
 {
     if (handle_ && n <= capacity_) return;
+    for (const SlotInfo& si : slots_)
+        if (si.pending) throw std::runtime_error("RecursivePatchwork: a frame larger than the capacity arrived while frames are in flight; "
+                                                 "call reserve() before submitting");
     size_t cap = capacity_ ? capacity_ : (1u << 18);
     while (cap < n) cap *= 2;
     if (handle_) { rpw_destroy(handle_); handle_ = nullptr; }
@@ -53,6 +83,78 @@ void RecursivePatchwork::ensure(size_t n)
         throw std::runtime_error(std::string("RecursivePatchwork: rpw_create failed: ") + rpw_last_error(nullptr));
     }
     capacity_ = cap;
+    if (depth_ && rpw_set_pipeline(handle_, depth_) != RPW_OK)
+        throw std::runtime_error(std::string("RecursivePatchwork: rpw_set_pipeline failed: ") + rpw_last_error(handle_));
+}
+
+void RecursivePatchwork::reserve(size_t max_points) { ensure(max_points); }
+
+void RecursivePatchwork::setPipelineDepth(unsigned depth)
+{
+    for (const SlotInfo& si : slots_) if (si.pending) throw std::runtime_error("RecursivePatchwork::setPipelineDepth: frames are in flight");
+    if (handle_ && rpw_set_pipeline(handle_, depth) != RPW_OK)
+        throw std::runtime_error(std::string("RecursivePatchwork: rpw_set_pipeline failed: ") + rpw_last_error(handle_));
+    depth_ = depth;
+    slots_.assign(depth, SlotInfo());
+}
+
+void RecursivePatchwork::submitFrame(unsigned slot, const std::vector<Point3D>& points)
+{
+    if (slot >= depth_) throw std::runtime_error("RecursivePatchwork::submitFrame: no such slot (setPipelineDepth)");
+    ensure(points.size());
+    const rpw_status rc = rpw_submit(handle_, slot, points.empty() ? nullptr : &points[0].x, (uint32_t)points.size(), 0);
+    if (rc != RPW_OK) throw std::runtime_error(std::string("RecursivePatchwork: rpw_submit failed: ") + rpw_last_error(handle_));
+    SlotInfo& si = slots_[slot];
+    si.n = points.size(); si.step = 12; si.off[0] = 0; si.off[1] = 4; si.off[2] = 8; si.pending = true;
+}
+
+void RecursivePatchwork::submitPointCloud2(unsigned slot, const unsigned char* data, size_t n, unsigned point_step,
+                                           unsigned off_x, unsigned off_y, unsigned off_z)
+{
+    if (slot >= depth_) throw std::runtime_error("RecursivePatchwork::submitPointCloud2: no such slot (setPipelineDepth)");
+    ensure(n);
+    const rpw_status rc = rpw_submit_pointcloud2(handle_, slot, data, (uint32_t)n, point_step, off_x, off_y, off_z, 0);
+    if (rc != RPW_OK) throw std::runtime_error(std::string("RecursivePatchwork: rpw_submit_pointcloud2 failed: ") + rpw_last_error(handle_));
+    SlotInfo& si = slots_[slot];
+    si.n = n; si.step = point_step; si.off[0] = off_x; si.off[1] = off_y; si.off[2] = off_z; si.pending = true;
+}
+
+bool RecursivePatchwork::frameDone(unsigned slot)
+{
+    if (slot >= depth_ || !slots_[slot].pending) throw std::runtime_error("RecursivePatchwork::frameDone: the slot holds no frame");
+    int done = 0;
+    if (rpw_poll(handle_, slot, &done) != RPW_OK) throw std::runtime_error(std::string("RecursivePatchwork: rpw_poll failed: ") + rpw_last_error(handle_));
+    return done != 0;
+}
+
+std::pair<std::vector<Point3D>, std::vector<Point3D>> RecursivePatchwork::waitFrame(unsigned slot)
+{
+    if (slot >= depth_ || !slots_[slot].pending) throw std::runtime_error("RecursivePatchwork::waitFrame: the slot holds no frame");
+    SlotInfo& si = slots_[slot];
+    std::vector<unsigned char> labels(si.n);
+    rpw_frame_stats st;
+    const rpw_status rc = rpw_wait(handle_, slot, labels.data(), nullptr, &st);
+    si.pending = false;
+    if (rc != RPW_OK) throw std::runtime_error(std::string("RecursivePatchwork: rpw_wait failed: ") + rpw_last_error(handle_));
+    n_zone_last_ = st.n_zone;
+    // the frame as it was submitted still sits in the slot's pinned buffer
+    const unsigned char* data = reinterpret_cast<const unsigned char*>(rpw_slot_input(handle_, slot));
+    auto point = [&](size_t i) {
+        Point3D p; const unsigned char* r = data + i * si.step;
+        std::memcpy(&p.x, r + si.off[0], 4); std::memcpy(&p.y, r + si.off[1], 4); std::memcpy(&p.z, r + si.off[2], 4);
+        return p;
+    };
+    std::vector<Point3D> ground, non_ground;
+    if (st.n_zone < 3) {
+        for (size_t i = 0; i < si.n; ++i) if (labels[i] != RPW_LABEL_DROPPED) non_ground.push_back(point(i));
+        return {ground, non_ground};
+    }
+    for (size_t i = 0; i < si.n; ++i) {
+        if (labels[i] == RPW_LABEL_GROUND) ground.push_back(point(i));
+        else if (labels[i] == RPW_LABEL_NONGROUND) non_ground.push_back(point(i));
+    }
+    for (size_t i = 0; i < si.n; ++i) if (labels[i] == RPW_LABEL_OUTSIDE) non_ground.push_back(point(i));
+    return {ground, non_ground};
 }
 
 void RecursivePatchwork::setConfig(const PatchworkConfig& config)

@@ -49,8 +49,12 @@ class RecursivePatchwork {
 public:
     RecursivePatchwork(const PatchworkConfig& config = PatchworkConfig{});
     ~RecursivePatchwork();
-    RecursivePatchwork(const RecursivePatchwork&) = delete;
-    RecursivePatchwork& operator=(const RecursivePatchwork&) = delete;
+    // Copyable like the reference's class (which holds only its config, recursive_patchwork.hpp:70): a copy gets the
+    // config, the device and the pipeline depth, and an engine of its own (device buffers are never shared).
+    RecursivePatchwork(const RecursivePatchwork& other);
+    RecursivePatchwork& operator=(const RecursivePatchwork& other);
+    RecursivePatchwork(RecursivePatchwork&& other) noexcept;
+    RecursivePatchwork& operator=(RecursivePatchwork&& other) noexcept;
 
     // {ground_points, non_ground_points}, reference order (recursive_patchwork.cpp:402-425)
     std::pair<std::vector<Point3D>, std::vector<Point3D>>
@@ -66,6 +70,19 @@ public:
     std::pair<std::vector<Point3D>, std::vector<Point3D>>
     filterGroundPointCloud2(const unsigned char* data, size_t n, unsigned point_step,
                             unsigned off_x, unsigned off_y, unsigned off_z);
+
+    // Build-side addition: the same call with up to `depth` frames in flight (C-ABI rpw_submit / rpw_wait). A frame is
+    // submitted into a free slot and returns at once; waitFrame(slot) blocks until that frame is done and returns the
+    // pair filterGroundPoints would have returned for it. The frame is copied into the slot's pinned buffer at
+    // submission, so the caller's vector / message may be released right away. Slots finish independently.
+    void setPipelineDepth(unsigned depth);
+    unsigned pipelineDepth() const { return depth_; }
+    void reserve(size_t max_points);                       // capacity of every slot (frames must not grow past it while frames are in flight)
+    void submitFrame(unsigned slot, const std::vector<Point3D>& points);
+    void submitPointCloud2(unsigned slot, const unsigned char* data, size_t n, unsigned point_step,
+                           unsigned off_x, unsigned off_y, unsigned off_z);
+    bool frameDone(unsigned slot);
+    std::pair<std::vector<Point3D>, std::vector<Point3D>> waitFrame(unsigned slot);
 
     // Build-side addition: LidarFusion::fuseLidarPointClouds (reference src/lidar_fusion.cpp:42-86) followed by
     // filterGroundPoints in ONE device pass: the per-sensor yaw rotation and ego-radius removal run in the
@@ -100,6 +117,9 @@ private:
     unsigned n_zone_last_ = 0;
     unsigned sample_seed_ = 0;
     bool have_sample_seed_ = false;
+    unsigned depth_ = 0;
+    struct SlotInfo { size_t n = 0; unsigned step = 12, off[3] = {0, 4, 8}; bool pending = false; };
+    std::vector<SlotInfo> slots_;
 };
 
 // same utility as the reference (recursive_patchwork.hpp:90-105)

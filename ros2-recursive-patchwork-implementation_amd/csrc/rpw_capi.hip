@@ -94,6 +94,8 @@ struct rpw_handle {
     Workspace ws;                        // batch / one-frame calls
     std::vector<Slot*> slots;            // host-pointer pipeline
 
+    int debug_gather_only = 0;
+
     // trace
     int trace = 0;
     uint32_t nodes_cap = 0;
@@ -353,6 +355,7 @@ void fill_params(rpw_handle* h, Workspace& w, DevParams& p, const void* d_xyz, u
     // the trace buffer belongs to the handle: only its own workspace writes it
     const bool tracing = (&w == &h->ws) && h->trace && h->d_nodes;
     p.trace = tracing ? 1 : 0; p.nodes = tracing ? h->d_nodes : nullptr; p.node_count = w.d_ctrl + kBuckets; p.nodes_cap = tracing ? h->nodes_cap : 0;
+    p.gather_only = h->debug_gather_only;
 
 }
 
@@ -578,6 +581,26 @@ rpw_status rpw_get_batch_stats(rpw_handle* h, rpw_frame_stats* stats, uint32_t n
     RPW_HIP(h, hipSetDevice(h->device));
     RPW_HIP(h, hipStreamSynchronize(h->ws.last_stream));
     if (n_frames) RPW_HIP(h, hipMemcpy(stats, h->ws.d_stats, n_frames * sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
+    return RPW_OK;
+}
+
+rpw_status rpw_result_record_device(rpw_handle* h, int32_t* d_out, uint32_t n_frames, void* stream)
+{
+    if (!h || (n_frames && !d_out)) return RPW_ERR_INVALID;
+    Workspace& w = h->ws;
+    if (n_frames > w.last_frames) return fail(h, RPW_ERR_INVALID, "asked for %u frames, last batch had %u", n_frames, w.last_frames);
+    RPW_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (w.done_valid && s != w.last_stream) RPW_HIP(h, hipStreamWaitEvent(s, w.done_ev, 0));   // behind the batch, whatever the stream
+    launch_result_record(w.d_stats, d_out, n_frames, s);
+    RPW_HIP(h, hipGetLastError());
+    return RPW_OK;
+}
+
+rpw_status rpw_set_debug_gather_only(rpw_handle* h, int enable)
+{
+    if (!h) return RPW_ERR_INVALID;
+    h->debug_gather_only = enable ? 1 : 0;
     return RPW_OK;
 }
 

@@ -1708,6 +1708,8 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         __syncthreads();                               // the directory's LDS becomes the ring; the wave's own stores are ordered
     }
 
+    if (p.gather_only) return;                         // diagnostic: the binning pass ends here (per-patch compaction done)
+
     // zone < 3: the reference returns {{}, cleaned} before looking at any patch (recursive_patchwork.cpp:339-341)
     if (p.stats[frame].n_zone < 3u) {
         for (uint32_t i = lane; i < pd.n; i += kFit1Threads) p.labels[fo + p.sidx[pd.begin + i]] = RPW_LABEL_NONGROUND;
@@ -2032,6 +2034,17 @@ __global__ __launch_bounds__(kFit1Threads, 4) void w1_loop_bench_kernel(const fl
 // operation sits between two frames' kernels): its input is read in place from pinned host memory by bin_tile,
 // and its results are written to pinned host memory by frame_copy_out.
 // ------------------------------------------------------------------------------------------
+// per-frame result record of a batch, as four int32: ground points, non-ground points of the zone, patches, refits
+// (what the multi-GPU result gather exchanges: reference callers get exactly these counts, recursive_patchwork.cpp:421-423)
+__global__ __launch_bounds__(256) void result_record_kernel(const rpw_frame_stats* __restrict__ stats, int32_t* __restrict__ out, uint32_t n_frames)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const rpw_frame_stats st = stats[f];
+    out[4 * f] = (int32_t)st.n_ground; out[4 * f + 1] = (int32_t)(st.n_zone - st.n_ground);
+    out[4 * f + 2] = (int32_t)st.n_patches; out[4 * f + 3] = (int32_t)st.total_iterations;
+}
+
 // frame offsets / tile bases of a one-frame batch, and the zeroed control words (bucket counts, node count, class totals)
 __global__ __launch_bounds__(256) void frame_setup_kernel(uint32_t* offsets, uint32_t n, uint32_t tiles, uint32_t* ctrl, uint32_t ctrl_words)
 {
@@ -2095,6 +2108,10 @@ void launch_fit(const DevParams& p, hipStream_t s)
     if (grid == 0) return;
     if (fit_variant() == 1) hipLaunchKernelGGL(patch_fit1_kernel, dim3(grid), dim3(kFit1Threads), 0, s, p);
     else                    hipLaunchKernelGGL(patch_fit_kernel, dim3(grid), dim3(kFitThreads), 0, s, p);
+}
+void launch_result_record(const rpw_frame_stats* stats, int32_t* out, uint32_t n_frames, hipStream_t s)
+{
+    if (n_frames) hipLaunchKernelGGL(result_record_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, stats, out, n_frames);
 }
 void launch_frame_setup(uint32_t* offsets, uint32_t n, uint32_t tiles, uint32_t* ctrl, uint32_t ctrl_words, hipStream_t s)
 {

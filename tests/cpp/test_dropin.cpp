@@ -2,6 +2,7 @@
 // (reference test/test_recursive_patchwork.cpp:51-98,146-164), against
 // recursive_patchwork::RecursivePatchwork backed by the HIP library. Seeded instead of random_device.
 #include "recursive_patchwork.hpp"
+#include "rpw_oracle.h"      // the CPU oracle: the checker (tests only)
 
 #include <cassert>
 #include <cmath>
@@ -113,6 +114,60 @@ int main()
         for (size_t i = n_ground_sample; i < s1.size(); ++i) assert(std::abs(s1[i].z - 1.1f) <= 0.5f);
         auto rot = pw.rotatePoints2D({{1.f, 0.f, 3.f}}, 90.0f);
         assert(std::abs(rot[0].x) < 1e-6f && std::abs(rot[0].y - 1.f) < 1e-6f && rot[0].z == 3.f);
+    }
+
+    // sampleGroundAndObstacles against the oracle's restatement (recursive_patchwork.cpp:428-465 +
+    // point_cloud_processor.cpp:121-146, seeded mt19937 + rejection loop): element for element
+    {
+        const float heights[2] = {1.1f, 0.3f};
+        for (int round = 0; round < 2; ++round) {
+            auto pts = synthetic(round == 0 ? 30000 : 2500, 11 + round);      // the small cloud has fewer than 2000 ground points
+            pts.push_back(Point3D(1.0f, 1.0f, 1.2f));                          // inside the ego radius, in the height band: must go
+            PatchworkConfig cfg;
+            RecursivePatchwork pw(cfg);
+            pw.setSampleSeed(1234u + round);
+            auto got = pw.sampleGroundAndObstacles(pts, heights[round], 0.5f);
+            rpwo_config oc = {cfg.sensor_height, cfg.max_range, cfg.num_sectors, cfg.max_iter, cfg.adaptive_seed_height ? 1 : 0,
+                              cfg.th_seeds, cfg.th_dist, cfg.th_outlier, cfg.filtering_radius, cfg.max_split_depth};
+            std::vector<float> want(pts.size() * 3);
+            uint32_t n_want = 0;
+            const int rc = rpwo_sample_ground_and_obstacles(&oc, &pts[0].x, (uint32_t)pts.size(), heights[round], 0.5f, 1234u + round, want.data(), &n_want);
+            assert(rc == 0);
+            assert(got.size() == n_want && n_want > 0);
+            for (size_t i = 0; i < got.size(); ++i) assert(std::memcmp(&got[i], &want[3 * i], 12) == 0);
+            std::printf("sample: %u points equal to the oracle's\n", n_want);
+        }
+    }
+
+    // pipeline: frames in flight give the same pairs as the synchronous call, whatever the order of the waits;
+    // a copy of the object is an engine of its own with the same config
+    {
+        std::vector<std::vector<Point3D>> fr = {synthetic(20000, 31), synthetic(50000, 32), synthetic(777, 33), synthetic(120000, 34), {}};
+        PatchworkConfig cfg; cfg.num_sectors = 12;
+        RecursivePatchwork pw(cfg);
+        pw.reserve(120000);
+        pw.setPipelineDepth(3);
+        RecursivePatchwork ref = pw;                                           // copy: own handle, same config
+        assert(ref.getConfig().num_sectors == 12 && ref.pipelineDepth() == 3);
+        const unsigned order[5] = {2, 0, 1, 1, 0};
+        size_t next = 0, checked = 0;
+        std::vector<int> in_slot(3, -1);
+        for (unsigned s = 0; s < 3 && next < fr.size(); ++s) { pw.submitFrame(s, fr[next]); in_slot[s] = (int)next++; }
+        for (unsigned k = 0; checked < fr.size(); ++k) {
+            unsigned s = order[k % 5];
+            while (in_slot[s] < 0) s = (s + 1) % 3;
+            auto got = pw.waitFrame(s);
+            auto want = ref.filterGroundPoints(fr[(size_t)in_slot[s]]);
+            assert(got.first.size() == want.first.size() && got.second.size() == want.second.size());
+            for (size_t i = 0; i < want.first.size(); ++i) assert(std::memcmp(&got.first[i], &want.first[i], 12) == 0);
+            for (size_t i = 0; i < want.second.size(); ++i) assert(std::memcmp(&got.second[i], &want.second[i], 12) == 0);
+            ++checked; in_slot[s] = -1;
+            if (next < fr.size()) { pw.submitFrame(s, fr[next]); in_slot[s] = (int)next++; }
+        }
+        bool threw = false;
+        try { (void)pw.waitFrame(0); } catch (const std::exception&) { threw = true; }
+        assert(threw);                                                         // nothing in flight
+        std::printf("pipeline: %zu frames equal to the synchronous call\n", checked);
     }
 
     // empty input: both empty

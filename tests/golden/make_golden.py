@@ -35,6 +35,9 @@ CASES = [
     ("c4", 0, dict(max_iter=0)),
     ("c5", 0, dict(max_split_depth=6)),
     ("c5", 0, dict(max_split_depth=6, max_iter=0)),
+    # natural recursion (no max_iter = 0 forcing): far-field clutter + tight th_dist, fits split to the configured depth
+    ("rough", 0, dict(max_split_depth=3, th_dist=0.0005)),
+    ("rough", 1, dict(max_split_depth=6, th_dist=0.0005)),
 ]
 
 

@@ -39,6 +39,11 @@ class OStats(C.Structure):
     ]
 
 
+class OBenchResult(C.Structure):
+    _fields_ = [("single_thread_median_ms", C.c_double), ("single_thread_frames", C.c_uint32), ("threads", C.c_uint32),
+                ("hardware_concurrency", C.c_uint32), ("frames_done", C.c_uint64), ("elapsed_s", C.c_double)]
+
+
 NODE_DTYPE = np.dtype([
     ("patch", "<i4"), ("depth", "<i4"), ("start", "<u4"), ("len", "<u4"), ("kind", "<i4"),
     ("iterations", "<i4"), ("n_inliers", "<u4"), ("split_axis", "<i4"), ("split_value", "<f4"),
@@ -80,6 +85,14 @@ def lib():
                                                 C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_uint32)]
         L.rpwo_fuse.restype = C.c_int
         L.rpwo_fuse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.rpwo_sample_ground_and_obstacles.restype = C.c_int
+        L.rpwo_sample_ground_and_obstacles.argtypes = [C.POINTER(OConfig), C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_uint32,
+                                                       C.c_void_p, C.POINTER(C.c_uint32)]
+        L.rpwo_set_chatter.restype = None
+        L.rpwo_set_chatter.argtypes = [C.c_int]
+        L.rpwo_bench_threads.restype = C.c_int
+        L.rpwo_bench_threads.argtypes = [C.POINTER(OConfig), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32,
+                                         C.POINTER(OBenchResult)]
         L.rpwo_eig3.restype = C.c_int
         L.rpwo_eig3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpwo_fit_plane.restype = None
@@ -168,3 +181,33 @@ def fuse(clouds, rotation_deg, ego_radius):
                          out.ctypes.data, src.ctypes.data, C.byref(n))
     assert rc == 0
     return out[: n.value].copy(), src[: n.value].copy(), raw, off
+
+
+def sample_ground_and_obstacles(xyz: np.ndarray, cfg: OConfig | None = None, target_height=1.1, base_tol=0.5, seed=0):
+    """sampleGroundAndObstacles restated (seeded): -> (k, 3) float32."""
+    cfg = cfg or make_config()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    out = np.empty((len(xyz), 3), np.float32)
+    k = C.c_uint32(0)
+    rc = lib().rpwo_sample_ground_and_obstacles(C.byref(cfg), xyz.ctypes.data, len(xyz), target_height, base_tol, seed,
+                                                out.ctypes.data, C.byref(k))
+    if rc:
+        raise RuntimeError(f"rpwo_sample_ground_and_obstacles failed: {rc}")
+    return out[: k.value].copy()
+
+
+def set_chatter(on: bool):
+    lib().rpwo_set_chatter(int(bool(on)))
+
+
+def bench_threads(frames, cfg: OConfig | None = None, n_threads: int = 0, seconds: float = 5.0, single_reps: int = 24) -> dict:
+    """Native CPU-baseline harness (no Python in the timed loops): single-thread median ms/frame, then frames/s with one
+    frame per std::thread on n_threads threads (0 = hardware_concurrency)."""
+    cfg = cfg or make_config()
+    xyz = np.ascontiguousarray(np.concatenate(frames, axis=0), dtype=np.float32)
+    off = np.zeros(len(frames) + 1, np.uint32); off[1:] = np.cumsum([len(f) for f in frames])
+    r = OBenchResult()
+    rc = lib().rpwo_bench_threads(C.byref(cfg), xyz.ctypes.data, off.ctypes.data, len(frames), n_threads, seconds, single_reps, C.byref(r))
+    if rc:
+        raise RuntimeError(f"rpwo_bench_threads failed: {rc}")
+    return {k: getattr(r, k) for k, _ in OBenchResult._fields_}

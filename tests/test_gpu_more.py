@@ -42,7 +42,10 @@ def test_hip_against_golden_fixtures(engine_factory, case):
 
 
 @pytest.mark.parametrize("name,kw", [("c5", dict(max_split_depth=6)), ("c5", dict(max_split_depth=6, max_iter=0)),
-                                     ("c4", dict(max_iter=3, max_split_depth=8, th_dist=0.05))])
+                                     ("c4", dict(max_iter=3, max_split_depth=8, th_dist=0.05)),
+                                     # NATURAL recursion (no max_iter = 0): fits lose their inliers and split to the configured depth
+                                     ("rough", dict(max_split_depth=3, th_dist=0.0005)), ("rough", dict(max_split_depth=6, th_dist=0.0005)),
+                                     ("rough", dict(max_split_depth=1000, th_dist=0.002, num_sectors=16))])
 def test_full_size_parity_with_trace(engine_factory, name, kw):
     xyz = W.make(name, 0)
     pc, oc = cfg_pair(**kw)
@@ -50,6 +53,42 @@ def test_full_size_parity_with_trace(engine_factory, name, kw):
     eng.set_trace(True, 1 << 18)
     labels, res, st = eng.segment(xyz, want_residual=True)
     assert_frame_parity(xyz, labels, res, st, eng.nodes(1 << 18), oc, tag=f"{name}/{kw}")
+    if name == "rough" and kw["max_split_depth"] <= 6:
+        assert st["max_depth"] == kw["max_split_depth"] and st["n_splits"] > 100      # the recursion did reach the configured depth
+
+
+def test_result_record_on_device_and_gather_only_diagnostic(engine_factory):
+    """rpw_result_record_device: the per-frame record the multi-GPU gather sends, written behind the batch on ANOTHER
+    stream (event dependency), equals the batch stats. The gather-only diagnostic launch leaves the handle usable."""
+    import torch
+    frames = [W.c2_hdl64(1), W.c1_test_cloud(2), W.c2_hdl64(2)[::2]]
+    off = np.zeros(len(frames) + 1, np.uint32); off[1:] = np.cumsum([len(f) for f in frames])
+    pc, oc = cfg_pair(max_split_depth=3)
+    eng = engine_factory(pc, max_points=int(off[-1]), max_frames=len(frames))
+    dev = torch.device("cuda", 0)
+    d_xyz = torch.from_numpy(np.concatenate(frames)).to(dev)
+    d_lab = torch.empty(int(off[-1]), dtype=torch.uint8, device=dev)
+    rec = torch.full((4 * len(frames),), -1, dtype=torch.int32, device=dev)
+    s_batch, s_gather = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    eng.segment_batch_device(d_xyz.data_ptr(), off, d_lab.data_ptr(), None, s_batch.cuda_stream)
+    eng.result_record_device(rec.data_ptr(), len(frames), s_gather.cuda_stream)
+    s_gather.synchronize()
+    got = rec.cpu().numpy().reshape(-1, 4)
+    st = eng.batch_stats(len(frames))
+    for f, xyz in enumerate(frames):
+        ref = O.segment(xyz, oc, want_residual=False, want_nodes=False)
+        assert got[f].tolist() == [ref.stats["n_ground"], ref.stats["n_zone"] - ref.stats["n_ground"], ref.stats["n_patches"],
+                                   ref.stats["total_iterations"]]
+        assert int(st["n_ground"][f]) == ref.stats["n_ground"]
+    eng.set_debug_gather_only(True)
+    eng.segment_batch_device(d_xyz.data_ptr(), off, d_lab.data_ptr(), None, s_batch.cuda_stream)
+    eng.set_debug_gather_only(False)
+    eng.segment_batch_device(d_xyz.data_ptr(), off, d_lab.data_ptr(), None, s_batch.cuda_stream)
+    torch.cuda.synchronize()
+    lab = d_lab.cpu().numpy()
+    for f, xyz in enumerate(frames):
+        assert np.array_equal(lab[off[f]: off[f + 1]], O.segment(xyz, oc, want_residual=False, want_nodes=False).labels)
 
 
 def test_batch_of_mixed_frames_device_resident(engine_factory):
@@ -145,9 +184,12 @@ def test_cpp_dropin_program(tmp_path):
     pkg = rpw_amd.PKG_DIR
     subprocess.check_call(["make", "-C", pkg, "-s", "librecursive_patchwork.so"])
     exe = str(tmp_path / "test_dropin")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(pkg, "cpp"), "-I", os.path.join(ROOT, "include"),
+    orc = os.path.join(ROOT, "oracle")
+    O.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(pkg, "cpp"), "-I", os.path.join(ROOT, "include"), "-I", orc,
                            "-ffp-contract=off", os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), "-o", exe,
-                           "-L", pkg, "-lrecursive_patchwork", "-lrpw_hip", f"-Wl,-rpath,{pkg}"])
+                           "-L", pkg, "-lrecursive_patchwork", "-lrpw_hip", "-L", orc, "-lrpw_oracle",
+                           f"-Wl,-rpath,{pkg}", f"-Wl,-rpath,{orc}"])
     out = subprocess.check_output([exe], text=True, timeout=300)
     assert "drop-in OK" in out
 

@@ -45,6 +45,17 @@ def test_config_mirror_field_for_field():
         assert getattr(c, name) == getattr(o, name), name
 
 
+def _stub_record(rank, frames):
+    """What rpw_result_record_device writes for a batch, from a stub segmenter (no GPU here): four int32 per frame.
+    The values depend on the rank AND on the frame, so a gather that mixes up ranks or frames cannot pass."""
+    import torch
+    rec = torch.empty(4 * len(frames), dtype=torch.int32)
+    for f, xyz in enumerate(frames):
+        n_ground = int((xyz[:, 2] < -1.5).sum())              # "ground" of the stub: low points
+        rec[4 * f: 4 * f + 4] = torch.tensor([n_ground, len(xyz) - n_ground, 50 + f + 10 * rank, 400 + 7 * f + rank], dtype=torch.int32)
+    return rec
+
+
 def _gloo_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
@@ -52,29 +63,37 @@ def _gloo_worker(rank, world, port, q):
     import torch.distributed as dist
     import bench
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    frames = bench.make_frames(2, rank)                      # each rank: its own frames (weak scaling)
-    counts = torch.tensor([len(f) for f in frames], dtype=torch.int32)
-    out = bench.gather_counts(counts, world)                 # the "trivial result gather"
+    frames = bench.make_frames(3, rank)                      # each rank: its own frames (weak scaling)
+    rec = _stub_record(rank, frames)
+    out = bench.gather_records(rec, world)                   # the result gather of one finished batch
     t = bench.max_over_ranks(0.5 + rank, torch.device("cpu"))
-    q.put((rank, out.tolist(), t, [int(rpw_amd.workloads.crc32(f)) for f in frames]))
+    q.put((rank, out.tolist(), rec.tolist(), t, [int(rpw_amd.workloads.crc32(f)) for f in frames]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_multi_gpu_plumbing_gloo_world2():
+def test_multi_gpu_result_gather_gloo_world2():
+    """Every rank ends with every rank's per-frame record -- in particular the n_ground of the frames it did NOT process --
+    in rank order, and world_size ranks contributed."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    world = 2
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, g0, t0, c0), (r1, g1, t1, c1) = res
-    assert g0 == g1 and len(g0) == 4                         # every rank sees every frame's record
+    (r0, g0, own0, t0, c0), (r1, g1, own1, t1, c1) = res
+    assert (r0, r1) == (0, 1)
+    assert g0 == g1 and len(g0) == world * 3 * 4             # every rank sees every frame's record
+    assert g0[:12] == own0 and g0[12:] == own1               # rank order; rank 0 holds rank 1's n_ground and vice versa
+    assert own0 != own1                                      # the two ranks did contribute different records
+    n_ground_other = g0[12::4]
+    assert all(v > 0 for v in n_ground_other)
     assert t0 == t1 == 1.5                                   # MAX over ranks
     assert c0 != c1                                          # ranks process different frames
 
