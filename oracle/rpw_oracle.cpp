@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstring>
 #include <iostream>
+#include <malloc.h>
 #include <limits>
 #include <numeric>
 #include <random>
@@ -719,6 +720,12 @@ int rpwo_bench_threads(const rpwo_config* cfg, const float* xyz, const uint32_t*
     if (!cfg || !xyz || !frame_off || !out || n_frames == 0) return 1;
     if (n_threads == 0) n_threads = std::thread::hardware_concurrency();
     if (n_threads == 0) n_threads = 1;
+    // The path allocates and frees multi-megabyte vectors all the time (as the reference does). Left at glibc's defaults
+    // each of them is an mmap / munmap pair, and hundreds of threads then queue on the process's address-space lock
+    // instead of computing. The baseline gets its best shot: big blocks stay in the heap, freed memory is kept.
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_ARENA_MAX, (int)(2 * n_threads));
     auto run = [&](uint32_t f, std::vector<uint8_t>& lab) {
         const uint32_t nf = frame_off[f + 1] - frame_off[f];
         if (lab.size() < nf) lab.resize(nf);

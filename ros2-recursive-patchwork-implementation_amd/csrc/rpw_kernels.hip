@@ -1180,7 +1180,7 @@ constexpr int kW1Ring = 3;           // ring slots: slot u lives in ring slot u 
 
 struct Fit1Shared {
     union {                            // the gather prologue is over before the first chain sweep
-        __attribute__((aligned(16))) float ring[kW1Ring * kSlotFloats];
+        __attribute__((aligned(16))) float ring[2 * kGatherTiles];     // sweeps: kW1Ring * kSlotFloats floats; fused pass: 3 * kFRow
         struct {
             uint32_t toff[kGatherTiles];
             uint32_t tsrc[kGatherTiles];
@@ -1189,6 +1189,7 @@ struct Fit1Shared {
     uint32_t hist[256];
     uint32_t stk[3 * kStackDepth];
 };
+static_assert(kW1Ring * kSlotFloats <= 2 * kGatherTiles, "the sweep ring must fit the union");
 
 struct W1 {
     const float *sx, *sy, *sz;         // patch-sorted SoA
@@ -1263,7 +1264,25 @@ struct MaskOut { uint32_t count, changed, differs_prev; };
 struct yes { static constexpr bool value = true; };
 struct no { static constexpr bool value = false; };
 
-template <int MODE>
+// one entry of the index list, 2 or 4 bytes wide (IW): nodes of up to 65536 slots use 16-bit entries
+template <int IW> __device__ __forceinline__ void il_store(__attribute__((address_space(1))) char* il, uint32_t pos, uint32_t v)
+{
+    if (IW == 2) *reinterpret_cast<__attribute__((address_space(1))) uint16_t*>(il + pos * 2u) = (uint16_t)v;
+    else         *reinterpret_cast<g_u32*>(il + pos * 4u) = v;
+}
+template <int IW> __device__ __forceinline__ uint32_t il_load(__attribute__((address_space(1))) const char* il, uint32_t pos)
+{
+    if (IW == 2) return (uint32_t)*reinterpret_cast<__attribute__((address_space(1))) const uint16_t*>(il + pos * 2u);
+    return *reinterpret_cast<const g_u32*>(il + pos * 4u);
+}
+
+// Plain mask pass (no chain): only kMaskOlder uses it in the kernel -- the list of the mask one iteration back, for the
+// residual of a period-2 fit that ends on the older mask. Inliers fill the list from the front in slot order; every
+// other lane stores into the list's LAST entry, which no reader ever reaches when the node has a non-inlier (and when
+// it has none, nobody stores there): every lane stores exactly once per chunk and the loop over the full chunks stays ONE
+// basic block (a conditional store is a branch around it, and a loop with branches gets a full s_waitcnt vmcnt(0) at its
+// head: the four-chunk prefetch then hides nothing). Only the last, partial chunk is handled with conditions.
+template <int MODE, int IW>
 __device__ __forceinline__ MaskOut w1_mask_loop(const NodeRef& nd, const MaskPrm& prm, int lane)
 {
     typedef __attribute__((address_space(1))) char g_char;
@@ -1294,12 +1313,9 @@ __device__ __forceinline__ MaskOut w1_mask_loop(const NodeRef& nd, const MaskPrm
         }
         in = in && ok;
         const unsigned long long m = ballot64(in);
-        const uint32_t rank = (uint32_t)mbcnt64(m);                // inliers among the lower lanes
-        // an inlier goes to cursor + rank; slot i as a non-inlier is number (i - cursor - rank) of them and goes to
-        // n - 1 - that (the tail of the list is never read)
-        const uint32_t pos = in ? cursor + rank : (n - 1u) - (i - cursor - rank);
-        if (FULL) *reinterpret_cast<g_u32*>(il + pos * 4u) = i;
-        else if (ok) *reinterpret_cast<g_u32*>(il + pos * 4u) = i;
+        const uint32_t pos = in ? cursor + (uint32_t)mbcnt64(m) : n - 1u;
+        if (FULL) il_store<IW>(il, pos, i);
+        else if (ok) il_store<IW>(il, pos, i);
         cursor += (uint32_t)__popcll(m);
     };
     // full chunks, four register sets, each reloaded right after use; chunks past the last full one are not loaded
@@ -1338,11 +1354,166 @@ __device__ __attribute__((noinline)) MaskOut w1_mask_pass(NodeRef nd_in, int mod
     const NodeRef nd = uni(nd_in);
     prm.cx = uni(prm.cx); prm.cy = uni(prm.cy); prm.cz = uni(prm.cz); prm.nx = uni(prm.nx); prm.ny = uni(prm.ny); prm.nz = uni(prm.nz);
     prm.thr = uni(prm.thr);
-    switch (uni((uint32_t)mode)) {
-    case kMaskPlane: return w1_mask_loop<kMaskPlane>(nd, prm, lane);
-    case kMaskSeed:  return w1_mask_loop<kMaskSeed>(nd, prm, lane);
-    default:         return w1_mask_loop<kMaskOlder>(nd, prm, lane);
+    (void)mode;
+    if (nd.n <= 65536u) return w1_mask_loop<kMaskOlder, 2>(nd, prm, lane);
+    return w1_mask_loop<kMaskOlder, 4>(nd, prm, lane);
+}
+
+// FUSED PASS = mask pass + centroid chain. The inliers of the NEW mask are found chunk by chunk, and their x, y, z go
+// straight into an LDS ring in slot order, where lanes 0..2 add them up sequentially (accumulator k in lane k, one
+// ds_read_b128 per four addends): the centroid sums of the new mask (point_cloud_processor.cpp:63-67) come out of the
+// same pass over the node that decides the mask, and the points are not read a second time for them. The chain runs one
+// chunk behind the predicate: while chunk c is evaluated (its loads were issued four chunks earlier), the complete
+// groups of four addends that the chunks before it left in the ring are added; their first reads are issued before the
+// chunk's arithmetic and return under it.
+constexpr int kFR = 512;                 // fused ring: addends per row (four chunks add at most 256, at most 67 more wait)
+constexpr int kFRow = kFR + 8;           // row stride in floats; entries kFR .. kFR+3 take the stores of lanes without an inlier
+struct FusedOut { uint32_t count, changed, differs_prev; float sx, sy, sz; };
+static_assert(3 * kFRow <= 2 * kGatherTiles, "the fused ring must fit the union");
+
+template <int MODE, int IW>
+__device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskPrm& prm, lds_f32* ring, int lane)
+{
+    typedef __attribute__((address_space(1))) char g_char;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4f lds_f4;
+    g_char* il = reinterpret_cast<g_char*>(nd.il);
+    const uint32_t n = nd.n;
+    const uint32_t nfull = n / kWave;
+    uint32_t cursor = 0;                                           // inliers so far = addends written
+    uint32_t consumed = 0;                                         // addends added so far (a multiple of 4 until the end)
+    bool changed = false, differs_prev = false;
+    float acc = 0.0f;                                              // Zero(), then += in slot order (lane k < 3: coordinate k)
+    const int row = lane < 3 ? lane : 2;
+    const lds_f32* rowp = ring + row * kFRow;
+    auto rd = [&](uint32_t g) -> v4f { return *reinterpret_cast<const lds_f4*>(rowp + (g & (uint32_t)(kFR - 1))); };
+    // eight groups of four addends in registers: the reads run eight groups (32 adds, ~260 cycles) ahead of the chain
+    v4f G0, G1, G2, G3, G4, G5, G6, G7;
+    auto prefetch = [&]() __attribute__((always_inline)) {
+        G0 = rd(consumed); G1 = rd(consumed + 4); G2 = rd(consumed + 8); G3 = rd(consumed + 12);
+        G4 = rd(consumed + 16); G5 = rd(consumed + 20); G6 = rd(consumed + 24); G7 = rd(consumed + 28);
+    };
+    // add the groups [consumed, limit): limit is a multiple of 4 that was <= cursor when prefetch() ran. Blocks of eight
+    // groups are ONE basic block each (add a group, request the group eight ahead into its register -- a branch per group
+    // made the compiler gather the requests at the bottom of the loop, right in front of their use); at most seven groups
+    // are left for the conditional tail, which only adds (the next prefetch() reloads every register).
+    auto drain = [&](uint32_t limit) __attribute__((always_inline)) {
+        if (limit <= consumed) return;
+        uint32_t g = consumed, ng = (limit - consumed) >> 2;
+        consumed = limit;
+#define RPW_W1_G(GK, OFF) { RPW_CHAIN4(acc, GK) GK = rd(g + 32u + (OFF)); __builtin_amdgcn_sched_barrier(0); }
+        for (; ng >= 8; ng -= 8, g += 32) {
+            __builtin_amdgcn_sched_barrier(0);
+            RPW_W1_G(G0, 0) RPW_W1_G(G1, 4) RPW_W1_G(G2, 8) RPW_W1_G(G3, 12) RPW_W1_G(G4, 16) RPW_W1_G(G5, 20) RPW_W1_G(G6, 24) RPW_W1_G(G7, 28)
+        }
+#undef RPW_W1_G
+        if (ng > 0) { RPW_CHAIN4(acc, G0) }
+        if (ng > 1) { RPW_CHAIN4(acc, G1) }
+        if (ng > 2) { RPW_CHAIN4(acc, G2) }
+        if (ng > 3) { RPW_CHAIN4(acc, G3) }
+        if (ng > 4) { RPW_CHAIN4(acc, G4) }
+        if (ng > 5) { RPW_CHAIN4(acc, G5) }
+        if (ng > 6) { RPW_CHAIN4(acc, G6) }
+    };
+    auto step = [&](const P4& r, uint32_t c, auto full) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full)::value;
+        const uint32_t i = c * kWave + lane;
+        const bool ok = FULL || i < n;
+        bool in;
+        if (MODE == kMaskPlane) {
+            const float d = plane_dist(r.x, r.y, r.z, prm.cx, prm.cy, prm.cz, prm.nx, prm.ny, prm.nz);
+            in = d < prm.thr;
+            const bool old = r.m & 1u, prev = (r.m >> 1) & 1u;
+            changed |= ok && (in != old);
+            differs_prev |= ok && (in != prev);
+            const uint8_t nb = (uint8_t)((in ? 1u : 0u) | ((r.m & 0x7fu) << 1));
+            if (FULL) nd.m[i] = nb; else if (ok) nd.m[i] = nb;
+        } else {
+            in = r.z < prm.thr;
+            if (FULL) nd.m[i] = in ? 1 : 0; else if (ok) nd.m[i] = in ? 1 : 0;
+        }
+        in = in && ok;
+        const unsigned long long m = ballot64(in);
+        const uint32_t p = cursor + (uint32_t)mbcnt64(m);
+        // (selections by bit mask, not by ?: -- two selects on one condition were turned into an if / else with a store
+        // in each arm, i.e. into branches inside the chunk)
+        const uint32_t sel = 0u - (uint32_t)in;
+        // index list (for the covariance sweep): an inlier to its place, everybody else into the last entry
+        const uint32_t ip = (p & sel) | ((n - 1u) & ~sel);
+        if (FULL) il_store<IW>(il, ip, i);
+        else if (ok) il_store<IW>(il, ip, i);
+        // centroid addends: an inlier to its place in the ring, everybody else into the dump entries
+        const uint32_t lp = ((p & (uint32_t)(kFR - 1)) & sel) | (((uint32_t)kFR + ((uint32_t)lane & 3u)) & ~sel);
+        lds_f32* w = ring + lp;
+        w[0] = r.x; w[kFRow] = r.y; w[2 * kFRow] = r.z;
+        cursor += (uint32_t)__popcll(m);
+    };
+    // Four full chunks per round: the reads of the groups the earlier rounds completed, then the four chunks' arithmetic
+    // as ONE basic block (so that the waits for their loads count precisely), then the adds of those groups.
+    // The first round is PEELED out of the loop: the wait counts inside a loop must hold for the way it is entered as
+    // well, and entered straight from the four back-to-back prologue loads they came out as vmcnt(7) where the steady
+    // state allows vmcnt(15) -- every chunk then waited for loads issued one chunk earlier.
+    uint32_t c = 0;
+    if (nfull >= 4) {
+        P4 r0 = w1_load(nd, 0 * kWave + lane), r1 = w1_load(nd, 1 * kWave + lane), r2 = w1_load(nd, 2 * kWave + lane), r3 = w1_load(nd, 3 * kWave + lane);
+        const uint32_t lastfull = (nfull - 1u) * kWave;
+        auto round = [&]() __attribute__((always_inline)) {
+            const uint32_t lim_ = cursor & ~3u;
+            prefetch();
+            // (the reloads clamp to the last full chunk: loads past it would be wasted, never wrong)
+            const uint32_t b4 = (c + 4) * kWave, b5 = b4 + kWave, b6 = b5 + kWave, b7 = b6 + kWave;
+            __builtin_amdgcn_sched_barrier(0);
+            step(r0, c, yes());     r0 = w1_load(nd, (b4 < lastfull ? b4 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            step(r1, c + 1, yes()); r1 = w1_load(nd, (b5 < lastfull ? b5 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            step(r2, c + 2, yes()); r2 = w1_load(nd, (b6 < lastfull ? b6 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            step(r3, c + 3, yes()); r3 = w1_load(nd, (b7 < lastfull ? b7 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            drain(lim_);
+            c += 4;
+        };
+        round();
+        while (c + 4 <= nfull) round();
     }
+    for (; c < nfull; ++c) {                                       // up to three full chunks left
+        const P4 r = w1_load(nd, c * kWave + lane);
+        const uint32_t lim_ = cursor & ~3u; prefetch(); step(r, c, yes()); drain(lim_);
+    }
+    if (nfull * kWave < n) {                                       // the partial chunk
+        const uint32_t i = nfull * kWave + lane;
+        const P4 r = w1_load(nd, i < n ? i : n - 1u);
+        const uint32_t lim_ = cursor & ~3u; prefetch(); step(r, nfull, no()); drain(lim_);
+    }
+    // what the last chunk left: the complete groups, then the last 1..3 addends padded with -0.0f (the exact identity)
+    {
+        const uint32_t lim = cursor & ~3u;
+        prefetch(); drain(lim);
+        if (cursor > lim) {
+            if (lane < 12) {                                       // entries cursor .. lim+3 of the three rows
+                const uint32_t e = cursor + ((uint32_t)lane & 3u);
+                if (e < lim + 4u) ring[(lane >> 2) * kFRow + (e & (uint32_t)(kFR - 1))] = -0.0f;
+            }
+            const v4f t = rd(lim);
+            RPW_CHAIN4(acc, t)
+        }
+    }
+    FusedOut o;
+    o.count = cursor;
+    o.changed = ballot64(changed) != 0ull ? 1u : 0u;
+    o.differs_prev = ballot64(differs_prev) != 0ull ? 1u : 0u;
+    o.sx = __shfl(acc, 0); o.sy = __shfl(acc, 1); o.sz = __shfl(acc, 2);
+    return o;
+}
+
+__device__ __attribute__((noinline)) FusedOut w1_fused_pass(NodeRef nd_in, int mode, MaskPrm prm, lds_f32* ring)
+{
+    const int lane = threadIdx.x;
+    const NodeRef nd = uni(nd_in);
+    prm.cx = uni(prm.cx); prm.cy = uni(prm.cy); prm.cz = uni(prm.cz); prm.nx = uni(prm.nx); prm.ny = uni(prm.ny); prm.nz = uni(prm.nz);
+    prm.thr = uni(prm.thr);
+    ring = (lds_f32*)(uintptr_t)uni((uint32_t)(uintptr_t)ring);
+    const bool narrow = nd.n <= 65536u;
+    if (uni((uint32_t)mode) == (uint32_t)kMaskPlane)
+        return narrow ? w1_fused_loop<kMaskPlane, 2>(nd, prm, ring, lane) : w1_fused_loop<kMaskPlane, 4>(nd, prm, ring, lane);
+    return narrow ? w1_fused_loop<kMaskSeed, 2>(nd, prm, ring, lane) : w1_fused_loop<kMaskSeed, 4>(nd, prm, ring, lane);
 }
 
 struct X3 { float x, y, z; };
@@ -1369,7 +1540,7 @@ template <int MODE> struct SweepRows { static constexpr int K = MODE == kSweepCo
 // scheduling barriers pin them there (left alone, the compiler gathers the LDS reads right in front of their use).
 //   steps 0-7  (first half of slot t, second half's reads)   : addends of slot t + 1 -> ring
 //   steps 8-15 (second half of slot t, reads of slot t + 1)   : point loads of slot t + 4, index load of slot t + 6
-template <int MODE, bool INDEXED>
+template <int MODE, int IW>        // IW: bytes per index list entry, 0 = the sweep runs over every slot of the node
 __device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count, const SweepPrm& prm, lds_f32* ring, int lane)
 {
     constexpr int K = SweepRows<MODE>::K;
@@ -1383,7 +1554,7 @@ __device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count
     // element j of slot u -> node slot (clamped: lanes past the end repeat the last element; their addends are replaced)
     auto index_of = [&](uint32_t u) -> uint32_t {
         const uint32_t j = u * kWave + lane, jc = j < last ? j : last;
-        return INDEXED ? *reinterpret_cast<const g_u32*>(il + jc * 4u) : jc;
+        return IW ? il_load<(IW ? IW : 4)>(il, jc) : jc;
     };
     auto point_of = [&](uint32_t idx) -> X3 {
         X3 q; q.x = ldg_f32(nd.x, idx); q.y = ldg_f32(nd.y, idx);
@@ -1493,13 +1664,14 @@ __device__ __attribute__((noinline)) Sums6 w1_chain_sweep(NodeRef nd_in, uint32_
     if (count == 0) return out;
     float acc;
     // (mode and indexed arrive in vector registers; the wave-uniform copy makes these scalar branches)
+    const bool narrow = nd.n <= 65536u;                // the width the pass that wrote the list used
     switch (__builtin_amdgcn_readfirstlane(mode)) {
-    case kSweepCov:   acc = w1_sweep_loop<kSweepCov, true>(nd, count, prm, ring, lane); break;
-    case kSweepXYZ:   acc = w1_sweep_loop<kSweepXYZ, true>(nd, count, prm, ring, lane); break;
-    case kSweepDist:  acc = w1_sweep_loop<kSweepDist, true>(nd, count, prm, ring, lane); break;
-    case kSweepRange: acc = w1_sweep_loop<kSweepRange, false>(nd, count, prm, ring, lane); break;
-    case kSweepXY:    acc = w1_sweep_loop<kSweepXY, false>(nd, count, prm, ring, lane); break;
-    default:          acc = w1_sweep_loop<kSweepVarXY, false>(nd, count, prm, ring, lane); break;
+    case kSweepCov:   acc = narrow ? w1_sweep_loop<kSweepCov, 2>(nd, count, prm, ring, lane) : w1_sweep_loop<kSweepCov, 4>(nd, count, prm, ring, lane); break;
+    case kSweepXYZ:   acc = narrow ? w1_sweep_loop<kSweepXYZ, 2>(nd, count, prm, ring, lane) : w1_sweep_loop<kSweepXYZ, 4>(nd, count, prm, ring, lane); break;
+    case kSweepDist:  acc = narrow ? w1_sweep_loop<kSweepDist, 2>(nd, count, prm, ring, lane) : w1_sweep_loop<kSweepDist, 4>(nd, count, prm, ring, lane); break;
+    case kSweepRange: acc = w1_sweep_loop<kSweepRange, 0>(nd, count, prm, ring, lane); break;
+    case kSweepXY:    acc = w1_sweep_loop<kSweepXY, 0>(nd, count, prm, ring, lane); break;
+    default:          acc = w1_sweep_loop<kSweepVarXY, 0>(nd, count, prm, ring, lane); break;
     }
     (void)indexed;
 #pragma unroll
@@ -1795,28 +1967,34 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         }
         NodeRef nd; nd.x = (g_cf32*)gx; nd.y = (g_cf32*)gy; nd.z = (g_cf32*)gz; nd.m = (g_u8*)gm; nd.il = (g_u32*)gl; nd.n = n;
         MaskPrm mp; mp.cx = mp.cy = mp.cz = 0.0f; mp.nx = mp.ny = 0.0f; mp.nz = 1.0f; mp.thr = z_th;
+        float cs[3];                                   // centroid sums of the current mask
         uint32_t count;
-        W1_PH(2, n, count = w1_mask_pass(nd, kMaskSeed, mp).count)
+        {   // seed mask + index list + centroid sums of the seeds, one pass
+            FusedOut fo_;
+            W1_PH(2, n, fo_ = w1_fused_pass(nd, kMaskSeed, mp, ring))
+            count = fo_.count; cs[0] = fo_.sx; cs[1] = fo_.sy; cs[2] = fo_.sz;
+            cx.addends += count;
+        }
         if (count < 3) {
             const Sel3 sel = w1_three_lowest(cx, s, n);
             for (uint32_t i = lane; i < n; i += kFit1Threads) gm[i] = (i == sel.v[0] || i == sel.v[1] || i == sel.v[2]) ? 1 : 0;
-            // the index list in slot order: the three slots, ascending
+            // the index list in slot order: the three slots, ascending (entries as wide as the passes read them)
             uint32_t a = sel.v[0], b = sel.v[1], c = sel.v[2], t;
             if (a > b) { t = a; a = b; b = t; }
             if (b > c) { t = b; b = c; c = t; }
             if (a > b) { t = a; a = b; b = t; }
-            if (lane == 0) { gl[0] = a; gl[1] = b; gl[2] = c; }
+            if (lane == 0) {
+                if (n <= 65536u) { uint16_t* g16 = reinterpret_cast<uint16_t*>(gl); g16[0] = (uint16_t)a; g16[1] = (uint16_t)b; g16[2] = (uint16_t)c; }
+                else { gl[0] = a; gl[1] = b; gl[2] = c; }
+            }
             count = 3;
-        }
-        __syncthreads();                               // index list and mask bytes written by this wave: drain before the reads
-        float cs[3];                                   // centroid sums of the current mask
-        auto centroid_sweep = [&](uint32_t m) {
+            __syncthreads();                           // index list and mask bytes written by this wave: drain before the reads
             Sums6 r;
-            W1_PH(3, m, r = w1_chain_sweep(nd, m, kSweepXYZ, 1, no_prm, ring))
-            cx.addends += m;
+            W1_PH(3, 3, r = w1_chain_sweep(nd, 3, kSweepXYZ, 1, no_prm, ring))
+            cx.addends += 3;
             cs[0] = r.v[0]; cs[1] = r.v[1]; cs[2] = r.v[2];
-        };
-        centroid_sweep(count);
+        }
+        __syncthreads();
 
         // ---- iterative refit (recursive_patchwork.cpp:186-217) ------------------------------------
         PlaneD pl; pl.cx = pl.cy = pl.cz = 0.0f; pl.nx = 0.0f; pl.ny = 0.0f; pl.nz = 1.0f; pl.residual = 3.402823466e+38f;
@@ -1848,9 +2026,10 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
             plane_of(count);
             ++iters;
             mp.cx = pl.cx; mp.cy = pl.cy; mp.cz = pl.cz; mp.nx = pl.nx; mp.ny = pl.ny; mp.nz = pl.nz; mp.thr = threshold;
-            MaskOut mo;
-            W1_PH(2, n, mo = w1_mask_pass(nd, kMaskPlane, mp))
+            FusedOut mo;                                         // new mask + its index list + its centroid sums
+            W1_PH(2, n, mo = w1_fused_pass(nd, kMaskPlane, mp, ring))
             const uint32_t newcount = mo.count;
+            cx.addends += newcount;
             const bool any_changed = mo.changed != 0, any_differs_prev = mo.differs_prev != 0;
             __syncthreads();
             if (!any_changed) {                                  // new_mask == ground_mask: converged
@@ -1869,11 +2048,11 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
                     final_bit = 1; count = oldcount;
                     have_plane = true; list_is_final = false;    // its residual is computed below, over the older mask
                 } else {
-                    centroid_sweep(count);
+                    cs[0] = mo.sx; cs[1] = mo.sy; cs[2] = mo.sz;
                 }
                 break;
             }
-            if (count >= 3) centroid_sweep(count);
+            cs[0] = mo.sx; cs[1] = mo.sy; cs[2] = mo.sz;
         }
 
         // ---- final plane (recursive_patchwork.cpp:220-228) ----------------------------------------
@@ -2022,8 +2201,8 @@ __global__ __launch_bounds__(kFit1Threads, 4) void w1_loop_bench_kernel(const fl
             acc += v.v[0];
         } else {
             MaskPrm mp; mp.cx = 0.0f; mp.cy = 0.0f; mp.cz = acc * 0.0f; mp.nx = 0.0f; mp.ny = 0.0f; mp.nz = 1.0f; mp.thr = 0.6f;
-            const MaskOut o = w1_mask_pass(nd, what - 16, mp);
-            acc += (float)o.count;
+            if (what == 18) { const MaskOut o = w1_mask_pass(nd, kMaskOlder, mp); acc += (float)o.count; }
+            else { const FusedOut o = w1_fused_pass(nd, what - 16, mp, ring); acc += (float)o.count + o.sx * 0.0f; }
         }
     }
     if (threadIdx.x == 0) out[blockIdx.x] = acc;
@@ -2106,7 +2285,15 @@ void launch_fit(const DevParams& p, hipStream_t s)
 {
     const uint32_t grid = p.n_frames * (uint32_t)p.P;
     if (grid == 0) return;
-    if (fit_variant() == 1) hipLaunchKernelGGL(patch_fit1_kernel, dim3(grid), dim3(kFit1Threads), 0, s, p);
+    // RPW_FIT_MAXWG=k (experiments): at most k workgroups of patch_fit1 per CU, by padding each with unused dynamic LDS
+    static const size_t pad = [] {
+        const char* e = getenv("RPW_FIT_MAXWG");
+        const int k = e ? atoi(e) : 0;
+        if (k <= 0 || k >= 16) return (size_t)0;
+        const size_t per = (160u * 1024u) / (size_t)k, stat = sizeof(Fit1Shared) + 64;
+        return per > stat ? ((per - stat) & ~(size_t)255) : (size_t)0;
+    }();
+    if (fit_variant() == 1) hipLaunchKernelGGL(patch_fit1_kernel, dim3(grid), dim3(kFit1Threads), pad, s, p);
     else                    hipLaunchKernelGGL(patch_fit_kernel, dim3(grid), dim3(kFitThreads), 0, s, p);
 }
 void launch_result_record(const rpw_frame_stats* stats, int32_t* out, uint32_t n_frames, hipStream_t s)

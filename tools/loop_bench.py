@@ -6,7 +6,7 @@ import rpw_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 eng = rpw_amd.Engine(rpw_amd.PatchworkConfig(), max_points=1024, max_frames=1)
 names = {0: "sweep xyz (3 rows)", 1: "sweep cov (6 rows)", 2: "sweep |d| (1 row)", 3: "sweep range (1 row, all slots)",
-         17: "mask pass plane", 16: "mask pass seed"}
+         17: "fused pass plane (mask + centroid chain)", 16: "fused pass seed (mask + centroid chain)"}
 pct = 56
 for blocks in (1, 256 * 4, 256 * 16, 256 * 32):
     print(f"--- {blocks} workgroups ({blocks / 256:.0f} per CU), node of {n} slots, {pct} % inliers")
