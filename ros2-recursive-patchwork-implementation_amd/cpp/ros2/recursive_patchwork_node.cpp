@@ -3,13 +3,15 @@
 // launch/recursive_patchwork.launch.py:11-67), backed by the MI355X library. PCL-free: the PointCloud2
 // bytes are converted by ../pointcloud2_io.hpp.
 //
-// NOT BUILT in this repository's image (no rclcpp). Build inside a ROS2 workspace:
-//   find_package(rclcpp REQUIRED) find_package(sensor_msgs REQUIRED) find_package(visualization_msgs REQUIRED)
-//   add_executable(recursive_patchwork_node cpp/ros2/recursive_patchwork_node.cpp cpp/recursive_patchwork.cpp)
-//   target_include_directories(... cpp include) ; target_link_libraries(... rpw_hip) ; ament_target_dependencies(...)
+// NOT BUILT in this repository's image (no rclcpp). Build inside a ROS2 workspace with the CMakeLists.txt / package.xml
+// beside this file (colcon build --packages-select recursive_patchwork); launch/recursive_patchwork.launch.py mirrors the
+// reference's launch arguments.
+#include <algorithm>
+#include <array>
 #include <chrono>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include <rclcpp/rclcpp.hpp>
 #include <sensor_msgs/msg/point_cloud2.hpp>
@@ -34,6 +36,10 @@ public:
         const double distance_threshold = declare_parameter<double>("distance_threshold", 0.1);
         const double angle_threshold = declare_parameter<double>("angle_threshold", 0.1);
         const int device = declare_parameter<int>("device", 0);               // addition: which MI355X
+        // addition: frames in flight. 1 = the reference's behaviour (a callback returns with its own frame published).
+        // k > 1: a callback submits its frame to a free pipeline slot and publishes the OLDEST frame in flight once k are
+        // (in order, k - 1 callbacks late): the GPU then works on k frames at a time instead of idling between callbacks.
+        depth_ = static_cast<unsigned>(std::min<int64_t>(32, std::max<int64_t>(1, declare_parameter<int>("frames_in_flight", 1))));
 
         PatchworkConfig config;                                               // reference mapping, node.cpp:36-40
         config.max_iter = max_iterations;
@@ -41,6 +47,7 @@ public:
         config.th_seeds = static_cast<float>(angle_threshold);
         RecursivePatchwork::setDevice(device);
         processor_ = std::make_unique<RecursivePatchwork>(config);            // throws if no MI355X: no CPU fallback
+        if (depth_ > 1) processor_->setPipelineDepth(depth_);
 
         sub_ = create_subscription<sensor_msgs::msg::PointCloud2>(
             input_topic_, rclcpp::SensorDataQoS(),
@@ -82,21 +89,44 @@ private:
         return out;
     }
 
+    void publishFrame(const std::pair<std::vector<Point3D>, std::vector<Point3D>>& r, const std_msgs::msg::Header& header)
+    {
+        if (!r.first.empty()) ground_pub_->publish(toMsg(r.first, header));             // empty clouds are not
+        if (!r.second.empty()) obstacles_pub_->publish(toMsg(r.second, header));        // published (node.cpp:116,136)
+        publishMarkers(r.first.size(), r.second.size(), header);
+    }
+
     void onCloud(const sensor_msgs::msg::PointCloud2& msg)
     {
         try {
             const auto t0 = std::chrono::high_resolution_clock::now();
             PointCloud2Layout L;
             if (!findLayout(msg, L)) { RCLCPP_ERROR(get_logger(), "PointCloud2 without FLOAT32 x/y/z fields"); return; }
-            const size_t n = static_cast<size_t>(msg.width) * msg.height;
-            if (L.bigendian || (L.point_step & 3u) || (L.off_x & 3u) || (L.off_y & 3u) || (L.off_z & 3u)) {
+            if (L.bigendian || (L.point_step & 3u) || (L.off_x & 3u) || (L.off_y & 3u) || (L.off_z & 3u) || !layoutFits(L)) {
                 RCLCPP_ERROR(get_logger(), "unsupported PointCloud2 layout"); return;
             }
-            // the message bytes go to the GPU as they are (no PCL hop, no host repacking)
-            auto [ground, obstacles] = processor_->filterGroundPointCloud2(msg.data.data(), n, L.point_step, L.off_x, L.off_y, L.off_z);
-            if (!ground.empty()) ground_pub_->publish(toMsg(ground, msg.header));            // empty clouds are not
-            if (!obstacles.empty()) obstacles_pub_->publish(toMsg(obstacles, msg.header));   // published (node.cpp:116,136)
-            publishMarkers(ground.size(), obstacles.size(), msg.header);
+            // a malformed message must not be read past its buffer (the reference's pcl::fromROSMsg checks the same)
+            if (!messageFits(msg.width, msg.height, msg.point_step, msg.row_step, msg.data.size())) {
+                RCLCPP_ERROR(get_logger(), "malformed PointCloud2: %u x %u records of %u bytes, row_step %u, but %zu data bytes",
+                             msg.width, msg.height, msg.point_step, msg.row_step, msg.data.size());
+                return;
+            }
+            const size_t n = static_cast<size_t>(msg.width) * msg.height;
+            if (n == 0) { RCLCPP_WARN(get_logger(), "Received empty point cloud"); return; }   // as the reference (node.cpp:72-75)
+            // rows with padding are packed first; the usual message (row_step == width * point_step) goes as it is
+            std::vector<uint8_t> packed;
+            const uint8_t* data = msg.data.data();
+            if (msg.row_step != msg.width * msg.point_step) { packed = packRows(data, msg.width, msg.height, msg.point_step, msg.row_step); data = packed.data(); }
+            if (depth_ <= 1) {
+                // the message bytes go to the GPU as they are (no PCL hop, no host repacking)
+                publishFrame(processor_->filterGroundPointCloud2(data, n, L.point_step, L.off_x, L.off_y, L.off_z), msg.header);
+            } else {
+                // pipeline: the slot this frame will use still holds the frame submitted depth_ callbacks ago: publish that one first
+                const unsigned slot = static_cast<unsigned>(seq_ % depth_);
+                if (in_flight_[slot]) { publishFrame(processor_->waitFrame(slot), headers_[slot]); in_flight_[slot] = false; }
+                processor_->submitPointCloud2(slot, data, n, L.point_step, L.off_x, L.off_y, L.off_z);
+                headers_[slot] = msg.header; in_flight_[slot] = true; ++seq_;
+            }
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
             RCLCPP_DEBUG(get_logger(), "processed %zu points in %.3f ms", n, ms);
         } catch (const std::exception& e) {
@@ -122,6 +152,10 @@ private:
 
     std::string input_topic_, ground_topic_, obstacles_topic_, visualization_topic_;
     std::unique_ptr<RecursivePatchwork> processor_;
+    unsigned depth_ = 1;
+    uint64_t seq_ = 0;
+    std::array<bool, 32> in_flight_{};
+    std::array<std_msgs::msg::Header, 32> headers_;
     rclcpp::Subscription<sensor_msgs::msg::PointCloud2>::SharedPtr sub_;
     rclcpp::Publisher<sensor_msgs::msg::PointCloud2>::SharedPtr ground_pub_, obstacles_pub_;
     rclcpp::Publisher<visualization_msgs::msg::MarkerArray>::SharedPtr markers_pub_;

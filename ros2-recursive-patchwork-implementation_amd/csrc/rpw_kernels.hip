@@ -1638,12 +1638,19 @@ __device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count
         RPW_W1_STEP_A(6, (void)0)                                                                           \
         RPW_W1_STEP_A(7, (void)0)                                                                           \
     }
-    for (uint32_t t = 0; t < nslots; t += 3) {
+    // three slots per round; the first round is peeled out of the loop (as in the fused pass: the wait counts of a loop
+    // must also hold for the way it is entered, and the prologue's back-to-back loads made its first wait a vmcnt(0))
+    auto round = [&](uint32_t t) __attribute__((always_inline)) -> bool {
         RPW_W1_SLOT(t, 0, P1, I1, I0)
-        if (t + 1 >= nslots) break;
+        if (t + 1 >= nslots) return false;
         RPW_W1_SLOT(t + 1, 1, P2, I2, I1)
-        if (t + 2 >= nslots) break;
+        if (t + 2 >= nslots) return false;
         RPW_W1_SLOT(t + 2, 2, P0, I0, I2)
+        return t + 3 < nslots;
+    };
+    if (round(0)) {
+        uint32_t t = 3;
+        while (round(t)) t += 3;
     }
 #undef RPW_W1_SLOT
 #undef RPW_W1_STEP_A

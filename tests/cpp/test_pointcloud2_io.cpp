@@ -28,6 +28,34 @@ int main()
     bool threw = false;
     try { PointCloud2Layout bad; bad.point_step = 8; pointsFromPointCloud2(v.data(), 1, bad); } catch (const std::runtime_error&) { threw = true; }
     assert(threw);
+    // offsets near 2^32 must not wrap through the "fits in the record" check
+    for (uint32_t off : {0xFFFFFFFCu, 0xFFFFFFF0u, 29u, 32u}) {
+        PointCloud2Layout w; w.point_step = 32; w.off_x = off;
+        assert(!layoutFits(w));
+        threw = false;
+        try { pointsFromPointCloud2(v.data(), 1, w); } catch (const std::runtime_error&) { threw = true; }
+        assert(threw);
+    }
+    { PointCloud2Layout ok; ok.point_step = 32; ok.off_x = 28; assert(layoutFits(ok)); }
+    // message-size checks of the subscriber: a truncated buffer, a row_step shorter than a row, overflowing products
+    assert(messageFits(2, 1, 32, 64, 64));
+    assert(!messageFits(2, 1, 32, 64, 63));            // truncated data
+    assert(!messageFits(2, 1, 32, 48, 64));            // row_step < width * point_step
+    assert(!messageFits(3, 2, 32, 96, 160));           // second row incomplete
+    assert(!messageFits(0x10000000u, 16, 16, 0xFFFFFFFFu, 1024));   // products beyond 32 bits
+    assert(!messageFits(1, 1, 0, 0, 0));
+    // rows with padding: height 2, width 2, point_step 16, row_step 40
+    {
+        std::vector<Point3D> g = {{1, 2, 3}, {4, 5, 6}, {7, 8, 9}, {10, 11, 12}};
+        std::vector<uint8_t> padded(80, 0xEE);
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) std::memcpy(&padded[r * 40 + c * 16], &g[r * 2 + c].x, 12);
+        assert(messageFits(2, 2, 16, 40, padded.size()));
+        auto packed = packRows(padded.data(), 2, 2, 16, 40);
+        assert(packed.size() == 64);
+        PointCloud2Layout P;
+        auto q = pointsFromPointCloud2(packed.data(), 4, P);
+        for (int i = 0; i < 4; ++i) assert(std::memcmp(&q[i], &g[i], 12) == 0);
+    }
     std::printf("pointcloud2_io OK\n");
     return 0;
 }

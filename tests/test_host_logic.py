@@ -118,3 +118,36 @@ def test_exact_block_sum_prototype_matches_sequential_sums(tmp_path):
                    check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert "MISMATCHES 0" in out and "resume strategy mismatches: 0" in out
+
+
+def test_ros2_package_glue(tmp_path):
+    """The ament package beside the node source: CMake configures WITHOUT ROS2 (rclcpp is found QUIETly and the node target is
+    left out), the launch file is valid Python declaring the reference's arguments with the reference's defaults
+    (reference launch/recursive_patchwork.launch.py:11-50), package.xml names the package like the reference."""
+    import ast
+    import subprocess
+    import xml.etree.ElementTree as ET
+    ros2 = os.path.join(rpw_amd.PKG_DIR, "cpp", "ros2")
+    out = subprocess.run(["cmake", "-S", ros2, "-B", str(tmp_path / "b")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "building the drop-in library only" in out.stdout or "ROS2 found" in out.stdout
+    src = open(os.path.join(ros2, "launch", "recursive_patchwork.launch.py")).read()
+    tree = ast.parse(src)
+    args = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") == "ARGUMENTS":
+            args = ast.literal_eval(node.value)
+    want = {"input_topic": "/lidar/points", "ground_topic": "/patchwork/ground", "obstacles_topic": "/patchwork/obstacles",
+            "visualization_topic": "/patchwork/visualization", "min_points": "100", "max_iterations": "50",
+            "distance_threshold": "0.1", "angle_threshold": "0.1"}
+    got = {a[0]: a[1] for a in args}
+    for k, v in want.items():
+        assert got[k] == v, k
+    pkg = ET.parse(os.path.join(ros2, "package.xml")).getroot()
+    assert pkg.find("name").text == "recursive_patchwork"
+    deps = {d.text for d in pkg.findall("depend")}
+    assert {"rclcpp", "sensor_msgs", "visualization_msgs"} <= deps
+    node_src = open(os.path.join(ros2, "recursive_patchwork_node.cpp")).read()
+    for name in ("input_topic", "ground_topic", "obstacles_topic", "visualization_topic", "min_points", "max_iterations",
+                 "distance_threshold", "angle_threshold", "messageFits", "Received empty point cloud"):
+        assert name in node_src, name
