@@ -237,7 +237,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 (default) is the configuration the metric is quoted on; the others are informational")
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (one batch); 0 = the workload's default (c2: 512)")
-    ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (HIP streams, one engine each)")
+    ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (HIP streams, one engine each)")
     ap.add_argument("--max-iter", type=int, default=100,
                     help="refit iterations; 0 = SURVEY.md 8d 'variant B' (every fit ends at once, so the recursion is forced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

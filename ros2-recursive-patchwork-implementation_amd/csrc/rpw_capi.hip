@@ -844,9 +844,6 @@ rpw_status rpw_get_nodes(rpw_handle* h, rpw_node* nodes, uint32_t cap, uint32_t*
     uint32_t cnt = 0;
     RPW_HIP(h, hipMemcpy(&cnt, h->ws.d_ctrl + kBuckets, sizeof(uint32_t), hipMemcpyDeviceToHost));
     *n_nodes = cnt;
-#if defined(RPW_STAMPS)
-    cnt = h->nodes_cap;   /* diagnostic build: return the whole buffer (stamps sit in its tail) */
-#endif
     uint32_t m = cnt < h->nodes_cap ? cnt : h->nodes_cap;
     if (m > cap) m = cap;
     if (m && nodes) RPW_HIP(h, hipMemcpy(nodes, h->d_nodes, (size_t)m * sizeof(rpw_node), hipMemcpyDeviceToHost));

@@ -9,12 +9,13 @@
 //   K3 patch_fit       scan of the patch's run lengths + gather of its runs (recursive_patchwork.cpp:372-378:
 //                      patch_points in zone order), then fitPlaneAndSplit / fitPlanePCA / computeCentroid / computeCovariance /
 //                      Eigen solve / computePlaneDistances / mask compare / split + recursion
-//                      (recursive_patchwork.cpp:77-308), one two-wave workgroup per (frame, patch)
+//                      (recursive_patchwork.cpp:77-308), ONE WAVE per (frame, patch): fused mask + centroid passes and
+//                      self-fed chain sweeps (see the comment in front of patch_fit1_kernel)
 //
 // Exactness: every sum the reference accumulates sequentially in binary32 (centroid,
 // covariance, residual, mean distance, variance) is accumulated here in the same order
-// by one lane per accumulator (the consumer wave); the producer wave only prepares the
-// addends. Built with -ffp-contract=off; divide and sqrt are correctly rounded.
+// by one lane per accumulator; the other lanes only prepare the addends.
+// Built with -ffp-contract=off; divide and sqrt are correctly rounded.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "rpw_internal.h"
@@ -379,226 +380,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
 }
 
 // ------------------------------------------------------------------------------------------
-// K3: per-patch gather + recursive plane fit. One 2-wave workgroup per (frame, patch):
-//   wave 0 = CONSUMER: runs nothing but the sequential binary32 add chains, one accumulator per
-//            lane, reading addends from an LDS ring (a dependent v_add_f32 chain retires one add
-//            per ~8 cycles on gfx950 and leaves every other issue slot empty);
-//   wave 1 = PRODUCER: streams the patch from L2/HBM with a two-chunk register prefetch, turns
-//            every slot into its addends (masked by -0.0f, an exact additive identity) and
-//            writes them transposed into the ring, two chunks ahead of the consumer.
-// Both waves share the data-parallel passes (bounding box, seeds, distances + mask compare,
-// order statistics, stable partition, labels).
+// small pieces shared by the plane-fit kernel's passes
 // ------------------------------------------------------------------------------------------
-constexpr int kFitThreads = 128;
-constexpr int kLdw  = 68;              // ring row stride in floats: 64 + 4 keeps the 6 chain lanes on distinct banks
-constexpr int kRing = 8;               // ring slots of 64 addends; the producer writes at most 3 slots past the last rendezvous
-constexpr int kSlotFloats = 6 * kLdw;
-
-struct Raw { float x, y, z; uint32_t m; };
-
-struct FitShared {
-    union {                            // the gather prologue is over before the first chained sweep
-        __attribute__((aligned(16))) float ring[kRing * kSlotFloats];
-        struct {
-            uint32_t toff[kGatherTiles];   // gather prologue: this patch's destination offset per tile of the frame
-            uint32_t tsrc[kGatherTiles];   // gather prologue: this patch's source slot per tile of the frame
-        } dir;
-    };
-    float bc[16];                      // broadcast: chain sums, plane
-    unsigned long long chain_addends;  // addends handed to the chains so far (per accumulator row); producer lane 0 only
-    uint32_t nslots;                   // chain_pass: number of compacted ring slots (kOpen while the producer is still working)
-    uint32_t red[2][8];                // per-wave partial counts / flags
-    float fred[2][8];                  // per-wave partial min / max
-    float rootbox[2][8];               // per-wave bounding box of the whole patch, taken by the gather
-    uint32_t hist[256];
-    uint32_t stk[3 * kStackDepth];
-};
-static_assert(sizeof(float) * kRing * kSlotFloats >= 2 * sizeof(uint32_t) * kGatherTiles, "the run directory must fit in the ring's space");
-
-struct FitCtx {
-    // raw pointers by value: taking the address of the kernel-argument struct would push it to scratch
-    const float *sx, *sy, *sz;
-    const uint8_t* mask;
-    FitShared* sh;
-    uint32_t base;        // absolute slot of the patch's first point
-    int lane, wave, tid;
-#if defined(RPW_STAMPS)       /* diagnostic build only: where block 0 spends its cycles */
-    mutable unsigned long long t_loop = 0, t_bar = 0, n_chunks = 0, n_pass = 0, t_pro = 0, t_epi = 0;
-#endif
-};
-
-#if defined(RPW_STAMPS)
-__device__ __forceinline__ unsigned long long stamp() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
-#define RPW_T(var) const unsigned long long var = stamp();
-#define RPW_ACC(field, a, b) cx.field += (b) - (a);
-#else
-#define RPW_T(var)
-#define RPW_ACC(field, a, b)
-#endif
-
-// LDS-only rendezvous of the two waves: outstanding global loads (the producer's prefetch) stay in flight
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// consumer side of the same rendezvous: it has written nothing, and its in-flight ds_reads target ring
-// slots the producer will not touch for two more steps, so it does not drain its LDS queue here
-__device__ __forceinline__ void lds_barrier_nowait() { asm volatile("s_barrier" ::: "memory"); }
-
-// The slot count the two waves share: relaxed workgroup-scope accesses that stay plain LDS instructions. (A volatile
-// access through a generic pointer becomes a system-scope flat access followed by a full wait on every counter.)
-// Their order against the ring data comes from the rendezvous barriers, which are compiler barriers as well.
-typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-__device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __hip_atomic_load((const lds_u32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void flag_store(uint32_t* p, uint32_t v) { __hip_atomic_store((lds_u32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// The producer's two stores of the slot count per sweep stay volatile generic stores (flat, system scope, followed by
-// a full wait). Measured, same session, 256 frames x 3 streams: producer volatile + consumer LDS load 54.8-56.6 k
-// frames/s; both volatile 54.0-54.2 k; both plain LDS 51.2-52.6 k; consumer volatile + producer LDS 49.7-50.0 k.
-// An explicit s_waitcnt vmcnt(0) after a plain LDS store does not reproduce the gain (51 k), so it is kept as measured.
-__device__ __forceinline__ void publish_slots(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
-
-// uniform base + 32-bit byte offset: the loads take the SGPR-base form, no 64-bit address arithmetic per lane
-// (rpw_create keeps the capacity under 2^30 slots)
-__device__ __forceinline__ float ldg_f32(const float* base, uint32_t slot) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + slot * 4u); }
-
-// Slot min(i, n-1) of chunk `chunk`: lanes (and whole prefetched chunks) past the end read the node's last slot again
-// instead of being masked off -- no exec juggling, no zero fill; chain_pass never lets them take part (n >= 1).
-__device__ __forceinline__ Raw load_raw(const FitCtx& cx, uint32_t s, uint32_t n, uint32_t chunk)
-{
-    Raw r;
-    const uint32_t i = chunk * kWave + cx.lane;
-    const uint32_t g = cx.base + s + (i < n ? i : n - 1u);
-    r.x = ldg_f32(cx.sx, g); r.y = ldg_f32(cx.sy, g); r.z = ldg_f32(cx.sz, g);
-    r.m = (uint32_t)cx.mask[g];                       // raw byte: nothing here may depend on a load's result
-    return r;
-}
+constexpr int kLdw  = 68;              // sweep ring row stride in floats: 64 + 4 keeps the 6 chain lanes on distinct banks
+constexpr int kSlotFloats = 6 * kLdw;  // one ring slot: 64 addends of up to 6 rows
 
 #define RPW_CHAIN4(ACC, Q) { ACC += (Q).x; ACC += (Q).y; ACC += (Q).z; ACC += (Q).w; }
-
-// One chained pass over the node [s, s+n): K sequential sums, accumulator k in consumer lane k.
-// make(raw, i, ok, out[K]) -> bool: turns slot i (node-relative) into its K addends, may update the
-// (ok says whether slot i exists: side effects must respect it, the returned predicate need not)
-// slot's mask byte, and says whether the slot takes part at all. Slots that do not are SKIPPED: the
-// producer compacts the addends (ballot + mbcnt keep slot order), so the chain is as long as the number
-// of participating slots, not as the node. post() runs once on the producer wave after its last chunk
-// (to publish its own partials). Result: sums[0..K-1] in every thread.
-//
-// Rendezvous protocol (one LDS-only barrier per 64 addends): the consumer adds ring slot t between
-// barrier t and barrier t+1 and prefetches slot t+1; the producer calls barrier b only once slots
-// <= b+1 are complete (or the input is exhausted, after padding the last slot with -0.0f and
-// publishing the slot count). Both sides execute exactly nslots + 1 barriers.
-constexpr uint32_t kOpen = 0xffffffffu;
-
-template <int K, class Make, class Post>
-__device__ __forceinline__ void chain_pass(const FitCtx& cx, uint32_t s, uint32_t n, Make make, Post post, float* sums)
-{
-    float* ring = cx.sh->ring;
-    uint32_t* nslots_pub = &cx.sh->nslots;
-    const uint32_t nch = (n + kWave - 1) / kWave;
-    if (cx.wave == 1) {
-        // ---------------- producer ----------------
-        uint32_t cursor = 0, next_barrier = 0;
-        if (cx.lane == 0) publish_slots(nslots_pub, kOpen);
-        // Two chunks per call: their arithmetic is independent, so the compiler interleaves the two
-        // dependency chains (a dependent VALU op issues every ~8 cycles, an independent one every 4).
-        auto fill2 = [&](uint32_t chunk, const Raw& ra, const Raw& rb) __attribute__((always_inline)) {
-            float va[K], vb[K];
-            const uint32_t ia = chunk * kWave + cx.lane, ib = ia + kWave;
-            // make() returns the slot's own predicate; whether the slot exists is ANDed in as a mask (scalar)
-            const bool oka = ia < n, okb = ib < n;
-            const bool pra = make(ra, ia, oka, va);
-            const bool prb = make(rb, ib, okb, vb);
-            const unsigned long long ma = ballot64(pra) & ballot64(oka), mb = ballot64(prb) & ballot64(okb);
-            const bool ina = pra && oka, inb = prb && okb;
-            const uint32_t ca = (uint32_t)__popcll(ma), cb = (uint32_t)__popcll(mb);
-            const uint32_t pa = cursor + (uint32_t)mbcnt64(ma);
-            const uint32_t pb = cursor + ca + (uint32_t)mbcnt64(mb);
-            // rendezvous that became due with the previous pair: made here, after this pair's arithmetic,
-            // when the previous pair's LDS writes have long landed (the wait inside is then free)
-            while ((cursor >> 6) >= next_barrier + 2) { RPW_T(tb0) lds_barrier(); RPW_T(tb1) RPW_ACC(t_bar, tb0, tb1) ++next_barrier; }
-            if (ina) {
-                float* dst = ring + ((pa >> 6) & (kRing - 1)) * kSlotFloats + (pa & 63u);
-#pragma unroll
-                for (int k = 0; k < K; ++k) dst[k * kLdw] = va[k];
-            }
-            if (inb) {
-                float* dst = ring + ((pb >> 6) & (kRing - 1)) * kSlotFloats + (pb & 63u);
-#pragma unroll
-                for (int k = 0; k < K; ++k) dst[k * kLdw] = vb[k];
-            }
-            cursor += ca + cb;
-        };
-        RPW_T(tp1)
-        // four register sets, each reloaded right after use: a chunk's loads are issued four chunks
-        // of work ahead, and no just-loaded register is ever copied
-        Raw r0 = load_raw(cx, s, n, 0), r1 = load_raw(cx, s, n, 1), r2 = load_raw(cx, s, n, 2), r3 = load_raw(cx, s, n, 3);
-        for (uint32_t c = 0; c < nch; c += 4) {
-            fill2(c, r0, r1);
-            r0 = load_raw(cx, s, n, c + 4); r1 = load_raw(cx, s, n, c + 5);
-            if (c + 2 < nch) {
-                fill2(c + 2, r2, r3);
-                r2 = load_raw(cx, s, n, c + 6); r3 = load_raw(cx, s, n, c + 7);
-            }
-        }
-        while ((cursor >> 6) >= next_barrier + 2) { lds_barrier(); ++next_barrier; }
-        // pad the last slot with the additive identity, publish the slot count, finish the rendezvous
-        const uint32_t nslots = (cursor + 63u) >> 6;
-        {
-            const uint32_t pos = cursor + (uint32_t)cx.lane;
-            if (pos < (nslots << 6)) {
-                float* dst = ring + ((pos >> 6) & (kRing - 1)) * kSlotFloats + (pos & 63u);
-#pragma unroll
-                for (int k = 0; k < K; ++k) dst[k * kLdw] = -0.0f;
-            }
-        }
-        if (cx.lane == 0) publish_slots(nslots_pub, nslots);
-        if (cx.lane == 0) cx.sh->chain_addends += cursor;      // statistics only (LDS, no register held for it)
-        while (next_barrier < nslots + 1) { lds_barrier(); ++next_barrier; }
-        RPW_T(tp2) RPW_ACC(t_loop, tp1, tp2)
-        post();
-    } else {
-        // ---------------- consumer ----------------
-        // Works in half slots (32 addends = 8 float4 per lane): while one half is being added, the
-        // next half is already on its way from LDS, so the add chain never waits for a ds_read.
-        const int row = cx.lane < K ? cx.lane : K - 1;
-        const float* rowp = ring + row * kLdw;
-        float acc = 0.0f;                                 // Zero(), then += in slot order
-        RPW_T(tc0)
-        lds_barrier_nowait();                             // barrier 0
-        RPW_T(tc1) RPW_ACC(t_pro, tc0, tc1)
-        uint32_t seen = flag_load(nslots_pub);                    // as of barrier 0: open => slots 0 and 1 exist
-        float4 A[8], B[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const float4*>(rowp + 4 * q);
-        bool exists = seen == kOpen || seen > 0u;
-        uint32_t t = 0;
-        while (exists) {
-            const uint32_t seen_t = flag_load(nslots_pub);        // as of barrier t; needed only after this step
-            const float* cur = rowp + (t & (kRing - 1)) * kSlotFloats + 32;
-            const float* nxt = rowp + ((t + 1) & (kRing - 1)) * kSlotFloats;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { B[q] = *reinterpret_cast<const float4*>(cur + 4 * q); RPW_CHAIN4(acc, A[q]) __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { A[q] = *reinterpret_cast<const float4*>(nxt + 4 * q); RPW_CHAIN4(acc, B[q]) __builtin_amdgcn_sched_barrier(0); }
-            RPW_T(tb0)
-            lds_barrier_nowait();                         // barrier t + 1
-            RPW_T(tb1) RPW_ACC(t_bar, tb0, tb1)
-            // if the producer was still open at barrier t it had completed slots <= t+1, so slot t+1 exists
-            ++t;
-            exists = seen_t == kOpen || t < seen_t;
-        }
-        RPW_T(tc2) RPW_ACC(t_loop, tc1, tc2)
-#if defined(RPW_STAMPS)
-        cx.n_chunks += t; cx.n_pass += 1;
-#endif
-        if (cx.lane < K) cx.sh->bc[cx.lane] = acc;
-    }
-    RPW_T(te0)
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; ++k) sums[k] = cx.sh->bc[k];
-    __syncthreads();
-    RPW_T(te1) RPW_ACC(t_epi, te0, te1)
-}
-
-struct NoPost { __device__ __forceinline__ void operator()() const {} };
 
 __device__ __forceinline__ float plane_dist(float x, float y, float z, float cx_, float cy_, float cz_, float nx, float ny, float nz)
 {
@@ -610,130 +397,9 @@ __device__ __forceinline__ float plane_dist(float x, float y, float z, float cx_
 
 struct PlaneD { float cx, cy, cz, nx, ny, nz, residual; };
 
-// centroid sums (sequential, slot order) over the slots whose mask bit `bit` is set
-__device__ __forceinline__ void centroid_sums(const FitCtx& cx, uint32_t s, uint32_t n, int bit, float* cs)
-{
-    chain_pass<3>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
-        const bool in = (r.m >> bit) & 1u;
-        v[0] = r.x; v[1] = r.y; v[2] = r.z;
-        return in;
-    }, NoPost(), cs);
-}
-
-// given the centroid sums of the m >= 3 inliers (mask bit `bit`): covariance pass + eigenvector
-__device__ __forceinline__ void plane_from_sums(const FitCtx& cx, uint32_t s, uint32_t n, int bit, uint32_t m, const float* cs, PlaneD& pl)
-{
-    const float fm = (float)m;
-    const float c0 = cs[0] / fm, c1 = cs[1] / fm, c2 = cs[2] / fm;
-    float cv[6];
-    chain_pass<6>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
-        const bool in = (r.m >> bit) & 1u;
-        // two-wide float arithmetic (v_pk_add_f32 / v_pk_mul_f32: each half is an ordinary IEEE binary32 operation)
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        const f2 dxy = f2{r.x, r.y} - f2{c0, c1};
-        const float dz = r.z - c2;
-        const f2 a = dxy * f2{dxy.x, dxy.x};            // dx*dx, dy*dx
-        const f2 b = f2{dxy.y, dz} * f2{dxy.y, dxy.x};  // dy*dy, dz*dx
-        const f2 c = f2{dz, dz} * f2{dxy.y, dz};        // dz*dy, dz*dz
-        v[0] = a.x;   // (0,0)
-        v[1] = a.y;   // (1,0)
-        v[2] = b.x;   // (1,1)
-        v[3] = b.y;   // (2,0)
-        v[4] = c.x;   // (2,1)
-        v[5] = c.y;   // (2,2)
-        return in;
-    }, NoPost(), cv);
-    const float fm1 = (float)(m - 1);
-    pl.cx = c0; pl.cy = c1; pl.cz = c2;
-    smallest_eigenvector(cv[0] / fm1, cv[1] / fm1, cv[2] / fm1, cv[3] / fm1, cv[4] / fm1, cv[5] / fm1, pl.nx, pl.ny, pl.nz);
-}
-
-__device__ __forceinline__ float residual_masked(const FitCtx& cx, uint32_t s, uint32_t n, int bit, uint32_t m, const PlaneD& pl)
-{
-    float r1[1];
-    chain_pass<1>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
-        const bool in = (r.m >> bit) & 1u;
-        v[0] = plane_dist(r.x, r.y, r.z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
-        return in;
-    }, NoPost(), r1);
-    return r1[0] / (float)m;
-}
-
 // monotone key: ascending unsigned order == ascending float order
 __device__ __forceinline__ uint32_t float_key(float v) { const uint32_t u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float key_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
-
-// exact order statistic: the value of rank k (0-based, ascending) among coordinate `axis` of the node
-__device__ __forceinline__ float select_rank(const FitCtx& cx, uint32_t s, uint32_t n, int axis, uint32_t k)
-{
-    const float* src = (axis == 0 ? cx.sx : (axis == 1 ? cx.sy : cx.sz)) + cx.base + s;
-    uint32_t* hist = cx.sh->hist;
-    uint32_t prefix = 0, pmask = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int j = cx.tid; j < 256; j += kFitThreads) hist[j] = 0;
-        __syncthreads();
-        for (uint32_t i = cx.tid; i < n; i += kFitThreads) {
-            const uint32_t key = float_key(src[i]);
-            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        // every wave scans the 256 bins on its own: lane l owns bins 4l..4l+3
-        const uint32_t h0 = hist[4 * cx.lane], h1 = hist[4 * cx.lane + 1], h2 = hist[4 * cx.lane + 2], h3 = hist[4 * cx.lane + 3];
-        const uint32_t tot = h0 + h1 + h2 + h3;
-        const uint32_t incl = wave_incl_scan(tot);
-        const uint32_t excl = incl - tot;
-        const bool mine = (k >= excl) && (k < incl);
-        const unsigned long long bm = ballot64(mine);
-        const int owner = __ffsll((long long)bm) - 1;
-        uint32_t bin = 0, before = 0;
-        if (mine) {
-            uint32_t c = excl;
-            if (k < c + h0) { bin = 4 * cx.lane; before = c; }
-            else { c += h0; if (k < c + h1) { bin = 4 * cx.lane + 1; before = c; }
-            else { c += h1; if (k < c + h2) { bin = 4 * cx.lane + 2; before = c; }
-            else { c += h2; bin = 4 * cx.lane + 3; before = c; } } }
-        }
-        bin = __shfl(bin, owner); before = __shfl(before, owner);
-        prefix |= bin << shift; pmask |= 255u << shift;
-        k -= before;
-        __syncthreads();
-    }
-    return key_float(prefix);
-}
-
-// libstdc++ std::partial_sort(idx, idx+3, idx+n, z[a] < z[b]) restated for "the 3 lowest z":
-// __heap_select over a 3-element max-heap; returns the three selected slots (set semantics).
-// Every wave computes the same answer on its own (no cross-wave traffic).
-__device__ __forceinline__ void three_lowest(const FitCtx& cx, uint32_t s, uint32_t n, uint32_t sel[3])
-{
-    const float* zs = cx.sz + cx.base + s;
-    uint32_t h0 = 0, h1 = 1, h2 = 2;
-    float z0 = zs[0], z1 = zs[1], z2 = zs[2];
-    // __adjust_heap(first, 0, 3, value) + __push_heap, value = (vi, vz)
-    auto adjust = [&](uint32_t vi, float vz) {
-        int hole;                                          // the larger child moves up into the root
-        if (z2 < z1) { h0 = h1; z0 = z1; hole = 1; } else { h0 = h2; z0 = z2; hole = 2; }
-        if (z0 < vz) { if (hole == 1) { h1 = h0; z1 = z0; } else { h2 = h0; z2 = z0; } h0 = vi; z0 = vz; }
-        else { if (hole == 1) { h1 = vi; z1 = vz; } else { h2 = vi; z2 = vz; } }
-    };
-    adjust(h0, z0);                                       // __make_heap: parent = 0, value = first[0]
-    for (uint32_t b = 3; b < n; b += kWave) {             // for (i = middle; i < last; ++i) if (z[i] < z[top]) pop_heap
-        const uint32_t i = b + cx.lane;
-        const float zi = i < n ? zs[i] : 0.0f;
-        unsigned long long done = 0ull;
-        for (;;) {
-            const bool want = i < n && zi < z0 && !((done >> cx.lane) & 1ull);
-            const unsigned long long cand = ballot64(want);
-            if (!cand) break;
-            const int l = __ffsll((long long)cand) - 1;
-            const uint32_t vi = (uint32_t)__shfl((int)i, l);
-            const float vz = __shfl(zi, l);
-            adjust(vi, vz);
-            done |= (l == 63) ? ~0ull : ((1ull << (l + 1)) - 1ull);   // lanes <= l were visited in order
-        }
-    }
-    sel[0] = h0; sel[1] = h1; sel[2] = h2;
-}
 
 struct PatchAcc { uint32_t nodes, splits, maxdepth, ground; unsigned long long iters; };
 
@@ -752,417 +418,13 @@ __device__ __forceinline__ void emit_node(const DevParams& p, int tid, int frame
     p.nodes[slot] = nd;
 }
 
-// 3 waves per SIMD (6 workgroups per CU): the waves of this kernel spend most of their time parked on the
-// rendezvous or on memory, so residency buys more than the few spilled registers cost (41 k -> 55 k frames/s)
-__global__ __launch_bounds__(kFitThreads, 3) void patch_fit_kernel(DevParams p)
-{
-    __shared__ FitShared sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    RPW_T(t_kernel0)
-
-    // ---- block -> patch, largest size bucket first --------------------------------------------
-    uint32_t linear;
-    {
-        const uint32_t cnt = p.bucket_count[kBuckets - 1 - lane];      // lane l: bucket 63-l (descending size)
-        const uint32_t incl = wave_incl_scan(cnt);
-        const uint32_t total = __shfl(incl, 63);
-        if (blockIdx.x >= total) return;
-        const unsigned long long bm = ballot64(blockIdx.x < incl);
-        const int l = __ffsll((long long)bm) - 1;
-        const uint32_t before = __shfl(incl - cnt, l);
-        linear = p.bucket_list[(size_t)(kBuckets - 1 - l) * p.list_stride + (blockIdx.x - before)];
-    }
-    const int frame = (int)(linear / (uint32_t)p.P), patch = (int)(linear % (uint32_t)p.P);
-    const PatchDesc pd = p.patches[linear];
-    const uint32_t fo = p.frame_off[frame];
-
-    if (wave == 1 && lane == 0) sh.chain_addends = 0ull;
-    FitCtx cx; cx.sx = p.sx; cx.sy = p.sy; cx.sz = p.sz; cx.mask = p.mask; cx.sh = &sh; cx.base = pd.begin; cx.lane = lane; cx.wave = wave; cx.tid = tid;
-    const rpw_config& cfg = p.cfg;
-    uint32_t* stk = sh.stk;
-
-    // ---- gather: assemble the patch's contiguous slots from its runs in the tile-sorted arrays ------------
-    // Run (tile t, this patch) lives at tile-slot tdir[t][patch] of tile t, is hist[t][patch] points long and goes
-    // to the patch slots that follow the runs of the earlier tiles (exclusive prefix over the tiles, made here).
-    // Destination slot d belongs to the LAST tile whose offset is <= d (empty runs repeat an offset). Input order
-    // is kept: runs in tile order.
-    {
-        const uint32_t t0 = p.tile_base[frame];
-        const uint32_t nt = p.tile_base[frame + 1] - t0;
-        const bool in_lds = nt <= (uint32_t)kGatherTiles;
-        uint32_t* toff = sh.dir.toff;                                       // destination offset of the run, per tile
-        uint32_t* tsrc = sh.dir.tsrc;                                       // frame-relative source slot of the run, per tile
-        const uint32_t* goff = p.hist + (size_t)t0 * p.PB + patch;      // stride PB: run lengths (offsets for a big frame)
-        const uint32_t* gdir = p.tdir + (size_t)t0 * p.PB + patch;      // stride PB
-        if (in_lds) {
-            // this patch's run length in every tile -> exclusive prefix = destination offset inside the patch;
-            // thread i owns tiles [i*per, (i+1)*per)
-            const uint32_t per = (nt + kFitThreads - 1) / kFitThreads;
-            const uint32_t ta = (uint32_t)tid * per, tb = ta + per < nt ? ta + per : nt;
-            uint32_t sum = 0;
-            for (uint32_t t = ta; t < tb; ++t) {
-                const uint32_t len = goff[(size_t)t * p.PB];
-                toff[t] = len; sum += len;
-                tsrc[t] = t * kTilePoints + gdir[(size_t)t * p.PB];
-            }
-            const uint32_t incl = wave_incl_scan(sum);
-            if (lane == 63) sh.red[wave][0] = incl;
-            __syncthreads();
-            uint32_t run = incl - sum + (wave == 1 ? sh.red[0][0] : 0u);
-            for (uint32_t t = ta; t < tb; ++t) { const uint32_t len = toff[t]; toff[t] = run; run += len; }
-        }
-        __syncthreads();
-        const uint32_t rel0 = in_lds ? 0u : pd.begin - fo;              // LDS offsets are patch-relative, global ones frame-relative
-        // Tile-sorted slot that feeds patch slot j: the LAST tile whose offset is <= d = rel0 + j. A fixed number of
-        // halving steps (the same for every lane and element), written with the STEP loop outside and the elements a
-        // thread handles in one round inside: their searches advance together, one LDS round trip per step for all of
-        // them (eight separate search loops cost 48 dependent round trips per round and made the gather 22 % of the
-        // largest patch's lifetime).
-        uint32_t top = 1; while (top * 2u < nt) top *= 2u;               // largest power of two < nt (nt >= 1), uniform
-        // kGatherWide independent elements per thread and round: their searches overlap in the LDS queue and their
-        // 16-byte loads are in flight together (the pass is latency-bound: HBM round trips, not bytes). The bounding
-        // box of the whole patch (the root node's early-out test) is taken here, while the points are in registers.
-        constexpr int kGatherWide = 8;
-        float xmn = 3.402823466e+38f, xmx = -3.402823466e+38f, ymn = xmn, ymx = xmx, zmn = xmn, zmx = xmx;
-        for (uint32_t j0 = tid; j0 < pd.n; j0 += kGatherWide * kFitThreads) {
-            uint32_t src[kGatherWide], d[kGatherWide], lo[kGatherWide]; float4 v4[kGatherWide];
-#pragma unroll
-            for (int u = 0; u < kGatherWide; ++u) { const uint32_t j = j0 + u * kFitThreads; d[u] = rel0 + (j < pd.n ? j : pd.n - 1u); lo[u] = 0; }
-            if (in_lds) {
-                for (uint32_t step = top; step > 0; step >>= 1) {
-                    uint32_t v[kGatherWide];
-#pragma unroll
-                    for (int u = 0; u < kGatherWide; ++u) { const uint32_t mid = lo[u] + step; v[u] = toff[mid < nt ? mid : nt - 1u]; }   // all reads first
-#pragma unroll
-                    for (int u = 0; u < kGatherWide; ++u) { const uint32_t mid = lo[u] + step; lo[u] = ((mid < nt) & (v[u] <= d[u])) ? mid : lo[u]; }
-                }
-#pragma unroll
-                for (int u = 0; u < kGatherWide; ++u) { const uint32_t o = toff[lo[u]], sb = tsrc[lo[u]]; src[u] = fo + sb + (d[u] - o); }
-            } else {
-                for (uint32_t step = top; step > 0; step >>= 1) {
-#pragma unroll
-                    for (int u = 0; u < kGatherWide; ++u) {
-                        const uint32_t mid = lo[u] + step, mc = mid < nt ? mid : nt - 1u;
-                        lo[u] = (mid < nt && goff[(size_t)mc * p.PB] <= d[u]) ? mid : lo[u];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < kGatherWide; ++u)
-                    src[u] = fo + lo[u] * kTilePoints + gdir[(size_t)lo[u] * p.PB] + (d[u] - goff[(size_t)lo[u] * p.PB]);
-            }
-#pragma unroll
-            for (int u = 0; u < kGatherWide; ++u) v4[u] = p.tp[src[u]];            // past the end: the last slot again
-#pragma unroll
-            for (int u = 0; u < kGatherWide; ++u) {
-                const uint32_t j = j0 + u * kFitThreads;
-                if (j < pd.n) {
-                    const uint32_t dst = pd.begin + j;
-                    p.sx[dst] = v4[u].x; p.sy[dst] = v4[u].y; p.sz[dst] = v4[u].z; p.sidx[dst] = __float_as_uint(v4[u].w);
-                }
-                // min/max are idempotent: a repeated last slot changes nothing
-                xmn = fminf(xmn, v4[u].x); xmx = fmaxf(xmx, v4[u].x); ymn = fminf(ymn, v4[u].y); ymx = fmaxf(ymx, v4[u].y);
-                zmn = fminf(zmn, v4[u].z); zmx = fmaxf(zmx, v4[u].z);
-            }
-        }
-        xmn = wave_min(xmn); xmx = wave_max(xmx); ymn = wave_min(ymn); ymx = wave_max(ymx); zmn = wave_min(zmn); zmx = wave_max(zmx);
-        if (lane == 0) { float* f = sh.rootbox[wave]; f[0] = xmn; f[1] = xmx; f[2] = ymn; f[3] = ymx; f[4] = zmn; f[5] = zmx; }
-        __syncthreads();
-    }
-
-    // zone < 3: the reference returns {{}, cleaned} before looking at any patch (recursive_patchwork.cpp:339-341)
-    if (p.stats[frame].n_zone < 3u) {
-        for (uint32_t i = tid; i < pd.n; i += kFitThreads) p.labels[fo + p.sidx[pd.begin + i]] = RPW_LABEL_NONGROUND;
-        return;
-    }
-
-    // ---- mean distance of the patch (recursive_patchwork.cpp:383-387): sequential sum of d ------
-    float mean_dist;
-    {
-        float sum[1];
-        chain_pass<1>(cx, 0, pd.n, [&](const Raw& r, uint32_t, bool ok, float* v) {
-            v[0] = sqrt_rn(r.x * r.x + r.y * r.y);
-            return true;
-        }, NoPost(), sum);
-        mean_dist = sum[0] / (float)pd.n;
-    }
-    const float rel_dist = mean_dist / cfg.filtering_radius;
-    const float threshold = cfg.th_dist * (1.0f + 0.2f * rel_dist);
-
-    PatchAcc pa; pa.nodes = 0; pa.splits = 0; pa.maxdepth = 0; pa.ground = 0; pa.iters = 0;
-    bool permuted = false;
-
-    int sp = 0;
-    if (tid == 0) { stk[0] = 0; stk[1] = pd.n; stk[2] = 0; }
-    sp = 1;
-    __syncthreads();
-
-    while (sp > 0) {
-        --sp;
-        const uint32_t s = stk[3 * sp], n = stk[3 * sp + 1];
-        const int depth = (int)stk[3 * sp + 2];
-        __syncthreads();
-        pa.nodes++;
-        if ((uint32_t)depth > pa.maxdepth) pa.maxdepth = (uint32_t)depth;
-        const float* gx = p.sx + cx.base + s;
-        const float* gy = p.sy + cx.base + s;
-        const float* gz = p.sz + cx.base + s;
-        uint8_t* gm = p.mask + cx.base + s;
-        const uint32_t* gi = p.sidx + cx.base + s;
-
-        // ---- early outs (recursive_patchwork.cpp:111-140) ---------------------------------------
-        int leaf_kind = -1;            // -1: run the fit
-        if (n < 3 || depth > cfg.max_split_depth) leaf_kind = RPW_NODE_REJECT;
-        if (leaf_kind < 0) {
-            float xmn = 3.402823466e+38f, xmx = -3.402823466e+38f, ymn = xmn, ymx = xmx, zmn = xmn, zmx = xmx;
-            const float (*box)[8] = sh.rootbox;                // the root node: the gather has taken its box already
-            if (depth > 0) {
-                box = sh.fred;
-                // four elements per thread and round in flight (the pass is latency-bound)
-                for (uint32_t i0 = tid; i0 < n; i0 += 4 * kFitThreads) {
-                    float x[4], y[4], z[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * kFitThreads, ic = i < n ? i : n - 1u; x[u] = gx[ic]; y[u] = gy[ic]; z[u] = gz[ic]; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        xmn = fminf(xmn, x[u]); xmx = fmaxf(xmx, x[u]); ymn = fminf(ymn, y[u]); ymx = fmaxf(ymx, y[u]);
-                        zmn = fminf(zmn, z[u]); zmx = fmaxf(zmx, z[u]);
-                    }
-                }
-                xmn = wave_min(xmn); xmx = wave_max(xmx); ymn = wave_min(ymn); ymx = wave_max(ymx);
-                zmn = wave_min(zmn); zmx = wave_max(zmx);
-                if (lane == 0) { float* f = sh.fred[wave]; f[0] = xmn; f[1] = xmx; f[2] = ymn; f[3] = ymx; f[4] = zmn; f[5] = zmx; }
-                __syncthreads();
-            }
-            xmn = fminf(box[0][0], box[1][0]); xmx = fmaxf(box[0][1], box[1][1]);
-            ymn = fminf(box[0][2], box[1][2]); ymx = fmaxf(box[0][3], box[1][3]);
-            zmn = fminf(box[0][4], box[1][4]); zmx = fmaxf(box[0][5], box[1][5]);
-            __syncthreads();
-            const float area = (xmx - xmn) * (ymx - ymn);
-            if (area < 25.0f && depth > 0) leaf_kind = RPW_NODE_SMALL;
-            else if ((zmx - zmn) < 0.05f && n > 10) leaf_kind = RPW_NODE_FLAT;
-        }
-        if (leaf_kind >= 0) {
-            const uint8_t lab = leaf_kind == RPW_NODE_REJECT ? RPW_LABEL_NONGROUND : RPW_LABEL_GROUND;
-            for (uint32_t i = tid; i < n; i += kFitThreads) p.labels[fo + gi[i]] = lab;
-            if (leaf_kind != RPW_NODE_REJECT) pa.ground += n;
-            emit_node(p, tid, frame, patch, depth, s, n, leaf_kind, 0, leaf_kind == RPW_NODE_REJECT ? 0u : n, -1, 0.0f, nullptr);
-            continue;
-        }
-
-        // ---- seeds (recursive_patchwork.cpp:149-182) ---------------------------------------------
-        float z_th;
-        if (cfg.adaptive_seed_height) {
-            z_th = cfg.sensor_height + 0.2f * rel_dist;
-        } else {
-            const uint32_t idx = (uint32_t)(0.1f * (float)n);     // static_cast<size_t>(0.1f * size)
-            z_th = select_rank(cx, s, n, 2, idx < n ? idx : n - 1) + cfg.th_seeds;
-        }
-        // Seed pass, fused: the producer writes the seed mask (z < z_th) and hands the consumer the
-        // centroid addends of that mask in the same sweep.
-        uint32_t count;
-        float cs[4];                       // centroid sums of the current mask (+ residual sum in the fused pass)
-        {
-            uint32_t seeds = 0;
-            chain_pass<3>(cx, s, n, [&](const Raw& r, uint32_t i, bool ok, float* v) {
-                const bool seed = r.z < z_th;
-                if (ok) gm[i] = seed ? 1 : 0;
-                seeds += (uint32_t)__popcll(ballot64(seed) & ballot64(ok));
-                v[0] = r.x; v[1] = r.y; v[2] = r.z;
-                return seed;
-            }, [&]() { if (lane == 0) sh.red[1][0] = seeds; }, cs);
-            count = sh.red[1][0];
-            __syncthreads();
-        }
-        if (count < 3) {
-            uint32_t sel[3];
-            three_lowest(cx, s, n, sel);
-            for (uint32_t i = tid; i < n; i += kFitThreads) gm[i] = (i == sel[0] || i == sel[1] || i == sel[2]) ? 1 : 0;
-            count = 3;
-            __syncthreads();
-            centroid_sums(cx, s, n, 0, cs);
-        }
-
-        // ---- iterative refit (recursive_patchwork.cpp:186-217) ------------------------------------
-        // Per iteration two chained sweeps: (1) covariance of the current mask -> plane; (2) FUSED:
-        // distances to that plane, new mask = d < threshold (stored, history shifted up one bit),
-        // centroid addends of the NEW mask and |d| addends of the OLD mask (= the residual the
-        // reference computes after the loop, recursive_patchwork.cpp:98-104, if this iteration converges).
-        PlaneD pl; pl.cx = pl.cy = pl.cz = 0.0f; pl.nx = 0.0f; pl.ny = 0.0f; pl.nz = 1.0f; pl.residual = 3.402823466e+38f;
-        int iters = 0;
-        int final_bit = 0;
-        bool have_plane = false, have_residual = false;   // pl / pl.residual belong to exactly the final mask
-        for (int iter = 0; iter < cfg.max_iter; ++iter) {
-            if (count < 3) break;
-            plane_from_sums(cx, s, n, 0, count, cs, pl);
-            ++iters;
-            uint32_t newcount = 0;
-            bool changed = false, differs_prev = false;
-            float fs[4];
-            chain_pass<4>(cx, s, n, [&](const Raw& r, uint32_t i, bool ok, float* v) {
-                const float d = plane_dist(r.x, r.y, r.z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
-                const bool nw = d < threshold;
-                const bool old = r.m & 1u, prev = (r.m >> 1) & 1u;
-                changed |= ok && (nw != old);
-                differs_prev |= ok && (nw != prev);
-                if (ok) gm[i] = (uint8_t)((nw ? 1u : 0u) | ((r.m & 0x7fu) << 1));
-                newcount += (uint32_t)__popcll(ballot64(nw) & ballot64(ok));
-                // Compacted by the NEW mask. Row 3 carries |d| of the slots that are also in the OLD mask: it
-                // is the old-mask residual exactly when the two masks coincide, which is the only case it is used.
-                v[0] = r.x; v[1] = r.y; v[2] = r.z;
-                v[3] = old ? d : -0.0f;
-                return nw;
-            }, [&]() {
-                const bool c = ballot64(changed) != 0ull, dp = ballot64(differs_prev) != 0ull;
-                if (lane == 0) { sh.red[1][0] = newcount; sh.red[1][1] = c ? 1u : 0u; sh.red[1][2] = dp ? 1u : 0u; }
-            }, fs);
-            newcount = sh.red[1][0];
-            const bool any_changed = sh.red[1][1] != 0, any_differs_prev = sh.red[1][2] != 0;
-            __syncthreads();
-            if (!any_changed) {                                  // new_mask == ground_mask: converged
-                pl.residual = fs[3] / (float)count;
-                have_plane = true; have_residual = true;
-                break;
-            }
-            const uint32_t oldcount = count;
-            count = newcount;
-            cs[0] = fs[0]; cs[1] = fs[1]; cs[2] = fs[2];
-            // Period-2 short cut: the new mask equals the mask two iterations ago, so the loop would
-            // alternate between the two masks until max_iter; its outcome is decided by parity alone.
-            if (iter >= 1 && !any_differs_prev && newcount >= 3 && iter + 1 < cfg.max_iter) {
-                const int remaining = cfg.max_iter - (iter + 1);
-                iters = cfg.max_iter;
-                if (remaining & 1) {                             // ends on the older mask: pl was fitted on it
-                    final_bit = 1; count = oldcount;
-                    have_plane = true;                           // its residual is recomputed below (row 3 is old AND new here)
-                }
-                break;
-            }
-        }
-
-        // ---- final plane (recursive_patchwork.cpp:220-228) ----------------------------------------
-        if (count < 3) {
-            pl.cx = pl.cy = pl.cz = 0.0f; pl.nx = 0.0f; pl.ny = 0.0f; pl.nz = 1.0f; pl.residual = 3.402823466e+38f;
-        } else {
-            if (!have_plane) plane_from_sums(cx, s, n, final_bit, count, cs, pl);     // cs = sums of the final mask
-            if (!have_residual) pl.residual = residual_masked(cx, s, n, final_bit, count, pl);
-        }
-
-        // ---- split? (recursive_patchwork.cpp:231-305) ---------------------------------------------
-        const float split_threshold = cfg.th_dist * (1.0f + 1.5f * (float)depth);
-        const uint32_t min_patch = 50u + 10u * (uint32_t)depth;
-        if (pl.residual > split_threshold && depth < cfg.max_split_depth && n >= min_patch) {
-            // variance of x and y about the centroid of ALL node points, sequential sums
-            float m2[2], v2[2];
-            chain_pass<2>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
-                v[0] = r.x; v[1] = r.y;
-                return true;
-            }, NoPost(), m2);
-            const float fn = (float)n;
-            const float mx = m2[0] / fn, my = m2[1] / fn;
-            chain_pass<2>(cx, s, n, [&](const Raw& r, uint32_t, bool ok, float* v) {
-                const float dx = r.x - mx, dy = r.y - my;
-                v[0] = dx * dx; v[1] = dy * dy;
-                return true;
-            }, NoPost(), v2);
-            const float var_x = v2[0] / fn, var_y = v2[1] / fn;
-            const int axis = (var_x > var_y) ? 0 : 1;
-            const float median = select_rank(cx, s, n, axis, n / 2);
-            const float* src = axis == 0 ? gx : gy;
-            // stable partition: left = (val <= median) keeps order, then right keeps order.
-            // Both waves walk every chunk (so both know the running offsets); a wave writes its own chunks.
-            uint32_t nleft = 0;
-            for (uint32_t b = 0; b < n; b += kWave) {
-                const uint32_t i = b + lane;
-                nleft += (uint32_t)__popcll(ballot64(i < n && src[i] <= median));
-            }
-            uint32_t lo = 0, ro = 0;
-            for (uint32_t b = 0, c = 0; b < n; b += kWave, ++c) {
-                const uint32_t i = b + lane;
-                const bool ok = i < n;
-                const float val = ok ? src[i] : 0.0f;
-                const bool left = ok && val <= median;
-                const unsigned long long ml = ballot64(left), mr = ballot64(ok && !left);
-                if (ok && (int)(c & 1u) == wave) {
-                    const uint32_t d = cx.base + s + (left ? lo + (uint32_t)mbcnt64(ml) : nleft + ro + (uint32_t)mbcnt64(mr));
-                    p.ax[d] = gx[i]; p.ay[d] = gy[i]; p.az[d] = gz[i];
-                }
-                lo += (uint32_t)__popcll(ml); ro += (uint32_t)__popcll(mr);
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += kFitThreads) {
-                const uint32_t g = cx.base + s + i;
-                p.sx[g] = p.ax[g]; p.sy[g] = p.ay[g]; p.sz[g] = p.az[g];
-            }
-            __syncthreads();
-            permuted = true;
-            pa.splits++;
-            pa.iters += (unsigned long long)iters;
-            emit_node(p, tid, frame, patch, depth, s, n, RPW_NODE_SPLIT, iters, count, axis, median, &pl);
-            // children inherit mean_dist; process the smaller one first (bounded stack)
-            const uint32_t nright = n - nleft;
-            if (tid == 0) {
-                const bool left_small = nleft <= nright;
-                const uint32_t big_s = left_small ? s + nleft : s, big_n = left_small ? nright : nleft;
-                const uint32_t sm_s = left_small ? s : s + nleft, sm_n = left_small ? nleft : nright;
-                stk[3 * sp] = big_s; stk[3 * sp + 1] = big_n; stk[3 * sp + 2] = (uint32_t)(depth + 1);
-                stk[3 * (sp + 1)] = sm_s; stk[3 * (sp + 1) + 1] = sm_n; stk[3 * (sp + 1) + 2] = (uint32_t)(depth + 1);
-            }
-            sp += 2;
-            __syncthreads();
-            continue;
-        }
-
-        // ---- FIT leaf: labels (and residuals) -----------------------------------------------------
-        pa.iters += (unsigned long long)iters;
-        for (uint32_t i0 = tid; i0 < n; i0 += 4 * kFitThreads) {          // four slots per thread and round in flight
-            uint32_t orig[4], m[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * kFitThreads, ic = i < n ? i : n - 1u; orig[u] = gi[ic]; m[u] = gm[ic]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t i = i0 + u * kFitThreads;
-                if (i >= n) continue;
-                p.labels[fo + orig[u]] = ((m[u] >> final_bit) & 1u) ? RPW_LABEL_GROUND : RPW_LABEL_NONGROUND;
-                if (p.residual) {
-                    float x, y, z;
-                    if (permuted) {
-                        P3 q = load_point(p, fo + orig[u]);
-                        if (p.sensors.n) (void)fuse_point(p, (uint32_t)frame, orig[u], q);     // the point as the fused cloud holds it
-                        x = q.x; y = q.y; z = q.z;
-                    }
-                    else { x = gx[i]; y = gy[i]; z = gz[i]; }
-                    p.residual[fo + orig[u]] = plane_dist(x, y, z, pl.cx, pl.cy, pl.cz, pl.nx, pl.ny, pl.nz);
-                }
-            }
-        }
-        pa.ground += count;
-        emit_node(p, tid, frame, patch, depth, s, n, RPW_NODE_FIT, iters, count, -1, 0.0f, &pl);
-    }
-
-#if defined(RPW_STAMPS)
-    if (blockIdx.x == 0 && lane == 0 && p.nodes) {
-        RPW_T(t_kernel1)
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.nodes + (p.nodes_cap - 8)) + 8 * wave;
-        d[0] = t_kernel1 - t_kernel0; d[1] = cx.t_loop; d[2] = cx.t_bar; d[3] = cx.n_chunks; d[4] = cx.n_pass; d[5] = cx.t_pro; d[6] = cx.t_epi; d[7] = pd.n;
-    }
-#endif
-    if (wave == 1 && lane == 0) atomicAdd((unsigned long long*)&p.stats[frame].chain_addends, sh.chain_addends);
-    if (tid == 0) {
-        rpw_frame_stats* st = p.stats + frame;
-        atomicAdd(&st->n_ground, pa.ground);
-        atomicAdd(&st->n_nodes, pa.nodes);
-        atomicAdd(&st->n_splits, pa.splits);
-        atomicMax(&st->max_depth, pa.maxdepth);
-        atomicAdd((unsigned long long*)&st->total_iterations, pa.iters);
-    }
-}
-
 // ==========================================================================================
-// K3, single-wave form: ONE WAVE per (frame, patch), nothing shared with any other wave.
+// K3 patch_fit1: ONE WAVE per (frame, patch), nothing shared with any other wave.
 //
-// The two-wave kernel above is bound by its producer: turning 64 points into compacted addends costs it ~170
-// instructions per ring slot (a lone wave issues one every 4 cycles: 680 cycles), while the chain needs
-// 64 x 8.2 = 525, and every slot costs a rendezvous on top. Here the work is cut differently:
+// (Round 1's kernel paired a producer wave with a consumer wave per patch. It was bound by its producer: turning 64
+// points into compacted addends cost it ~170 instructions per ring slot -- a lone wave issues one every ~5 cycles --
+// while the chain needs 64 x 8.2 = 525 cycles, and every slot cost a rendezvous on top: 64.8 k frames/s. DESIGN.md
+// section 4 keeps its measurements.) Here the work is cut differently:
 //   * a MASK PASS (data-parallel, no chain) evaluates the inlier predicate of every slot of the node, keeps the
 //     mask history byte and writes the slot numbers of the inliers, in slot order, into an index list;
 //   * a CHAIN SWEEP walks that list 64 inliers at a time: gather x, y, z, make the K addends, transpose them
@@ -2282,12 +1544,6 @@ void launch_scan(const DevParams& p, hipStream_t s)
     int parts = kScanThreads / (p.P + 4); if (parts > 16) parts = 16; if (parts < 1) parts = 1;      // as in the kernel
     hipLaunchKernelGGL(scan_offsets_kernel, dim3(p.frame_count), dim3(kScanThreads), (size_t)p.PB * (2 + parts) * 4, s, p);
 }
-// RPW_FIT=2 selects the two-wave producer / consumer kernel, anything else the single-wave kernel (A/B measurements)
-static int fit_variant()
-{
-    static const int v = [] { const char* e = getenv("RPW_FIT"); return (e && e[0] == '2') ? 2 : 1; }();
-    return v;
-}
 void launch_fit(const DevParams& p, hipStream_t s)
 {
     const uint32_t grid = p.n_frames * (uint32_t)p.P;
@@ -2300,8 +1556,7 @@ void launch_fit(const DevParams& p, hipStream_t s)
         const size_t per = (160u * 1024u) / (size_t)k, stat = sizeof(Fit1Shared) + 64;
         return per > stat ? ((per - stat) & ~(size_t)255) : (size_t)0;
     }();
-    if (fit_variant() == 1) hipLaunchKernelGGL(patch_fit1_kernel, dim3(grid), dim3(kFit1Threads), pad, s, p);
-    else                    hipLaunchKernelGGL(patch_fit_kernel, dim3(grid), dim3(kFitThreads), 0, s, p);
+    hipLaunchKernelGGL(patch_fit1_kernel, dim3(grid), dim3(kFit1Threads), pad, s, p);
 }
 void launch_result_record(const rpw_frame_stats* stats, int32_t* out, uint32_t n_frames, hipStream_t s)
 {
