@@ -95,7 +95,13 @@ def cpu_baseline(frames, ocfg_kw, seconds: float = 8.0):
     import oracle_lib as O
     cfg = O.make_config(**ocfg_kw)
     sample = frames[: min(len(frames), 64)]
-    r = O.bench_threads(sample, cfg, n_threads=0, seconds=seconds, single_reps=24)
+    # all hardware threads, and one thread per two of them (physical cores on an SMT-2 host): the better one is reported
+    r_all = O.bench_threads(sample, cfg, n_threads=0, seconds=seconds / 2, single_reps=24)
+    hw = int(r_all["hardware_concurrency"]) or 1
+    r_half = O.bench_threads(sample, cfg, n_threads=max(1, hw // 2), seconds=seconds / 2, single_reps=4) if hw > 1 else r_all
+    fps_all, fps_half = r_all["frames_done"] / r_all["elapsed_s"], r_half["frames_done"] / r_half["elapsed_s"]
+    r = r_all if fps_all >= fps_half else r_half
+    r = dict(r, single_thread_median_ms=r_all["single_thread_median_ms"], single_thread_frames=r_all["single_thread_frames"])
     # as shipped: the same single-thread run with the reference's prints, stdout -> /dev/null
     sys.stdout.flush()
     saved = os.dup(1)
@@ -119,6 +125,7 @@ def cpu_baseline(frames, ocfg_kw, seconds: float = 8.0):
         "sample": f"{r['frames_done']} frames of the bench batch ({len(sample)} distinct), one frame per std::thread on "
                   f"{r['threads']} threads, {r['elapsed_s']:.1f} s, native harness; single thread: median of "
                   f"{r['single_thread_frames']} frames after 3 warm-ups",
+        "frames_per_sec_by_threads": {str(int(r_all["threads"])): round(fps_all, 2), str(int(r_half["threads"])): round(fps_half, 2)},
         "single_thread_ms_per_frame": round(r["single_thread_median_ms"], 3),
         "single_thread_ms_per_frame_as_shipped_chatter_to_devnull": round(1e3 * float(np.median(times)), 3),
     }
