@@ -239,7 +239,7 @@ def host_path_legs(rpw_amd, cfg_kw, frames, local_rank, seconds=0.8, slots=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=126, help="timed steps (default: about one second)")
+    ap.add_argument("--steps", type=int, default=192, help="timed steps (default: a little over one second)")
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 (default) is the configuration the metric is quoted on; the others are informational")

@@ -45,7 +45,9 @@ def test_hip_against_golden_fixtures(engine_factory, case):
                                      ("c4", dict(max_iter=3, max_split_depth=8, th_dist=0.05)),
                                      # NATURAL recursion (no max_iter = 0): fits lose their inliers and split to the configured depth
                                      ("rough", dict(max_split_depth=3, th_dist=0.0005)), ("rough", dict(max_split_depth=6, th_dist=0.0005)),
-                                     ("rough", dict(max_split_depth=1000, th_dist=0.002, num_sectors=16))])
+                                     ("rough", dict(max_split_depth=1000, th_dist=0.002, num_sectors=16)),
+                                     # patches of more than 65536 points: the index list switches to 32-bit entries
+                                     ("c5", dict(num_sectors=1, max_split_depth=2)), ("c5", dict(num_sectors=2, max_iter=4, max_split_depth=1000, th_dist=0.01))])
 def test_full_size_parity_with_trace(engine_factory, name, kw):
     xyz = W.make(name, 0)
     pc, oc = cfg_pair(**kw)
