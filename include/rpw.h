@@ -243,7 +243,8 @@ rpw_status  rpw_debug_eig3(rpw_handle* h, const float* cov9, float* normal3, uin
 rpw_status  rpw_set_debug_gather_only(rpw_handle* h, int enable);
 /* Micro-benchmark of the two loops the plane-fit kernel lives in, on a synthetic node of n slots of which inlier_pct %
  * are inliers, one node per workgroup, `blocks` workgroups, `reps` passes each: what = 0..5 chain sweeps (centroid,
- * covariance, residual, range, xy, variance), 16..18 mask passes (seed, plane, older). ms = device time of the launch. */
+ * covariance, residual, range, xy, variance), 16..18 fused / mask passes (seed, plane, older); + 32: the same loop in the
+ * two-wave form (chain wave + helper wave). ms = device time of the launch. */
 rpw_status  rpw_debug_loop_bench(rpw_handle* h, int what, uint32_t n, uint32_t inlier_pct, int reps, uint32_t blocks, double* ms);
 /* Host evaluation of the same atan2f restatement (no device needed). */
 void        rpw_debug_angles_host(const float* x, const float* y, float* angle, uint32_t n);

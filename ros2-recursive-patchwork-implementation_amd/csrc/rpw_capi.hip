@@ -905,7 +905,9 @@ rpw_status rpw_debug_loop_bench(rpw_handle* h, int what, uint32_t n, uint32_t in
 {
     if (!h || !ms || n == 0 || blocks == 0 || reps <= 0 || inlier_pct > 100) return RPW_ERR_INVALID;
     if ((uint64_t)n * blocks > (1ull << 28)) return fail(h, RPW_ERR_CAPACITY, "loop bench: n * blocks too large");
-    if (!((what >= 0 && what <= 5) || (what >= 16 && what <= 18))) return fail(h, RPW_ERR_INVALID, "loop bench: unknown loop %d", what);
+    const int base_what = what & 31;
+    if ((what & ~63) || !((base_what >= 0 && base_what <= 5) || (base_what >= 16 && base_what <= 18)))
+        return fail(h, RPW_ERR_INVALID, "loop bench: unknown loop %d", what);
     RPW_HIP(h, hipSetDevice(h->device));
     const size_t total = (size_t)n * blocks;
     // synthetic node: a plane z ~ 0 with noise and 1 - inlier_pct % of points well above it; the index list holds the inliers
@@ -941,7 +943,7 @@ rpw_status rpw_debug_loop_bench(rpw_handle* h, int what, uint32_t n, uint32_t in
     if (e == hipSuccess) e = hipEventCreate(&eb);
     float t = 0.0f;
     if (e == hipSuccess) {
-        const uint32_t cnt = what < 16 ? (what == kSweepRangeMode || what >= 4 ? n : count) : n;
+        const uint32_t cnt = base_what < 16 ? (base_what == kSweepRangeMode || base_what >= 4 ? n : count) : n;
         launch_loop_bench(dx, dy, dz, dm, dil, n, cnt, what, 1, blocks, dout, nullptr);            // warm-up
         e = hipEventRecord(ea, nullptr);
         launch_loop_bench(dx, dy, dz, dm, dil, n, cnt, what, reps, blocks, dout, nullptr);

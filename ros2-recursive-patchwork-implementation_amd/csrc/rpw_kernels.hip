@@ -442,7 +442,7 @@ constexpr int kW1Ring = 3;           // ring slots: slot u lives in ring slot u 
 
 struct Fit1Shared {
     union {                            // the gather prologue is over before the first chain sweep
-        __attribute__((aligned(16))) float ring[2 * kGatherTiles];     // sweeps: kW1Ring * kSlotFloats floats; fused pass: 3 * kFRow
+        __attribute__((aligned(16))) float ring[2 * kGatherTiles];     // sweeps: kW1Ring * kSlotFloats floats; fused pass: kFSlots * kFSlotFloats
         struct {
             uint32_t toff[kGatherTiles];
             uint32_t tsrc[kGatherTiles];
@@ -450,6 +450,10 @@ struct Fit1Shared {
     };
     uint32_t hist[256];
     uint32_t stk[3 * kStackDepth];
+    // two-wave form only: the command the chain wave hands the helper wave, and the fused pass's hand-off words
+    uint32_t cmd[24];
+    uint32_t fcur[2];                  // inliers written up to the end of round r, in fcur[r & 1]
+    uint32_t fflags[2];                // changed / differs-from-the-mask-before, of the whole pass
 };
 static_assert(kW1Ring * kSlotFloats <= 2 * kGatherTiles, "the sweep ring must fit the union");
 
@@ -465,7 +469,13 @@ struct W1 {
 
 struct P4 { float x, y, z; uint32_t m; };
 
+// Ordering INSIDE one wave (a lane reads what another lane of the same wave wrote, in LDS or in global memory through the
+// CU's L1): earlier accesses complete before later ones start. No s_barrier: in the two-wave form these phases run on
+// the chain wave alone while the helper wave is parked at a barrier of its own.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
 typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) uint32_t lds_word;
 
 // The node a pass works on, as plain pointers to its first slot (by value: the passes are real functions, not inlined
 // copies -- six inlined sweeps made the compiler hoist six sets of loop invariants over the whole node loop, 253 VGPRs).
@@ -628,10 +638,62 @@ __device__ __attribute__((noinline)) MaskOut w1_mask_pass(NodeRef nd_in, int mod
 // chunk behind the predicate: while chunk c is evaluated (its loads were issued four chunks earlier), the complete
 // groups of four addends that the chunks before it left in the ring are added; their first reads are issued before the
 // chunk's arithmetic and return under it.
-constexpr int kFR = 512;                 // fused ring: addends per row (four chunks add at most 256, at most 67 more wait)
-constexpr int kFRow = kFR + 8;           // row stride in floats; entries kFR .. kFR+3 take the stores of lanes without an inlier
+// fused ring: kFSlots slots of 64 addends x 3 rows (row stride kLdw, like a sweep slot); addend p lives in slot (p / 64) % kFSlots,
+// column p % 64. Columns 64..67 of slot 0 take the stores of the lanes that hold no inlier.
+constexpr int kFSlots = 8;
+constexpr int kFSlotFloats = 3 * kLdw;
+__device__ __forceinline__ uint32_t fused_ring_pos(uint32_t p) { return ((p >> 6) & (uint32_t)(kFSlots - 1)) * (uint32_t)kFSlotFloats + (p & 63u); }
 struct FusedOut { uint32_t count, changed, differs_prev; float sx, sy, sz; };
-static_assert(3 * kFRow <= 2 * kGatherTiles, "the fused ring must fit the union");
+
+// The centroid chain of a fused pass: whole slots of 64 addends, added with the sweeps' statically scheduled routine (one
+// ds_read_b128 per four dependent adds, half a slot of reads in flight). A dynamic loop over groups of four addends cost
+// ~21 cycles per add; this costs ~9.
+struct FusedChain {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4f lds_f4;
+    float acc = 0.0f;                  // Zero(), then += in slot order (lane k < 3: coordinate k)
+    uint32_t cs = 0;                   // slots added so far
+    bool have_a = false;               // A holds the first half of slot cs
+    v4f A[8], B[8];
+    // add the slots [cs, avail): all of them are complete in the ring
+    __device__ __forceinline__ void consume(const lds_f32* rowp, uint32_t avail)
+    {
+        while (cs < avail) {
+            const lds_f32* sp = rowp + (cs & (uint32_t)(kFSlots - 1)) * (uint32_t)kFSlotFloats;
+            if (!have_a) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const lds_f4*>(sp + 4 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { B[q] = *reinterpret_cast<const lds_f4*>(sp + 32 + 4 * q); RPW_CHAIN4(acc, A[q]) __builtin_amdgcn_sched_barrier(0); }
+            ++cs;
+            if (cs < avail) {
+                const lds_f32* np = rowp + (cs & (uint32_t)(kFSlots - 1)) * (uint32_t)kFSlotFloats;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { A[q] = *reinterpret_cast<const lds_f4*>(np + 4 * q); RPW_CHAIN4(acc, B[q]) __builtin_amdgcn_sched_barrier(0); }
+                have_a = true;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { RPW_CHAIN4(acc, B[q]) }
+                have_a = false;
+            }
+        }
+    }
+    // the end of the pass: `cursor` addends were written; the last slot is padded with -0.0f (the exact identity) and added
+    __device__ __forceinline__ void finish(lds_f32* ring, const lds_f32* rowp, uint32_t cursor, int lane)
+    {
+        consume(rowp, cursor >> 6);
+        if (cursor & 63u) {
+            if ((uint32_t)lane >= (cursor & 63u)) {
+                lds_f32* w = ring + fused_ring_pos((cursor & ~63u) + (uint32_t)lane);
+                w[0] = -0.0f; w[kLdw] = -0.0f; w[2 * kLdw] = -0.0f;
+            }
+            have_a = false;                                        // (a prefetched half of this slot would predate the padding)
+            consume(rowp, (cursor >> 6) + 1u);
+        }
+    }
+};
+static_assert(kFSlots * kFSlotFloats <= 2 * kGatherTiles, "the fused ring must fit the union");
 
 template <int MODE, int IW>
 __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskPrm& prm, lds_f32* ring, int lane)
@@ -643,40 +705,10 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
     const uint32_t n = nd.n;
     const uint32_t nfull = n / kWave;
     uint32_t cursor = 0;                                           // inliers so far = addends written
-    uint32_t consumed = 0;                                         // addends added so far (a multiple of 4 until the end)
     bool changed = false, differs_prev = false;
-    float acc = 0.0f;                                              // Zero(), then += in slot order (lane k < 3: coordinate k)
+    FusedChain ch;
     const int row = lane < 3 ? lane : 2;
-    const lds_f32* rowp = ring + row * kFRow;
-    auto rd = [&](uint32_t g) -> v4f { return *reinterpret_cast<const lds_f4*>(rowp + (g & (uint32_t)(kFR - 1))); };
-    // eight groups of four addends in registers: the reads run eight groups (32 adds, ~260 cycles) ahead of the chain
-    v4f G0, G1, G2, G3, G4, G5, G6, G7;
-    auto prefetch = [&]() __attribute__((always_inline)) {
-        G0 = rd(consumed); G1 = rd(consumed + 4); G2 = rd(consumed + 8); G3 = rd(consumed + 12);
-        G4 = rd(consumed + 16); G5 = rd(consumed + 20); G6 = rd(consumed + 24); G7 = rd(consumed + 28);
-    };
-    // add the groups [consumed, limit): limit is a multiple of 4 that was <= cursor when prefetch() ran. Blocks of eight
-    // groups are ONE basic block each (add a group, request the group eight ahead into its register -- a branch per group
-    // made the compiler gather the requests at the bottom of the loop, right in front of their use); at most seven groups
-    // are left for the conditional tail, which only adds (the next prefetch() reloads every register).
-    auto drain = [&](uint32_t limit) __attribute__((always_inline)) {
-        if (limit <= consumed) return;
-        uint32_t g = consumed, ng = (limit - consumed) >> 2;
-        consumed = limit;
-#define RPW_W1_G(GK, OFF) { RPW_CHAIN4(acc, GK) GK = rd(g + 32u + (OFF)); __builtin_amdgcn_sched_barrier(0); }
-        for (; ng >= 8; ng -= 8, g += 32) {
-            __builtin_amdgcn_sched_barrier(0);
-            RPW_W1_G(G0, 0) RPW_W1_G(G1, 4) RPW_W1_G(G2, 8) RPW_W1_G(G3, 12) RPW_W1_G(G4, 16) RPW_W1_G(G5, 20) RPW_W1_G(G6, 24) RPW_W1_G(G7, 28)
-        }
-#undef RPW_W1_G
-        if (ng > 0) { RPW_CHAIN4(acc, G0) }
-        if (ng > 1) { RPW_CHAIN4(acc, G1) }
-        if (ng > 2) { RPW_CHAIN4(acc, G2) }
-        if (ng > 3) { RPW_CHAIN4(acc, G3) }
-        if (ng > 4) { RPW_CHAIN4(acc, G4) }
-        if (ng > 5) { RPW_CHAIN4(acc, G5) }
-        if (ng > 6) { RPW_CHAIN4(acc, G6) }
-    };
+    const lds_f32* rowp = ring + row * kLdw;
     auto step = [&](const P4& r, uint32_t c, auto full) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full)::value;
         const uint32_t i = c * kWave + lane;
@@ -705,9 +737,9 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
         if (FULL) il_store<IW>(il, ip, i);
         else if (ok) il_store<IW>(il, ip, i);
         // centroid addends: an inlier to its place in the ring, everybody else into the dump entries
-        const uint32_t lp = ((p & (uint32_t)(kFR - 1)) & sel) | (((uint32_t)kFR + ((uint32_t)lane & 3u)) & ~sel);
+        const uint32_t lp = (fused_ring_pos(p) & sel) | ((64u + ((uint32_t)lane & 3u)) & ~sel);
         lds_f32* w = ring + lp;
-        w[0] = r.x; w[kFRow] = r.y; w[2 * kFRow] = r.z;
+        w[0] = r.x; w[kLdw] = r.y; w[2 * kLdw] = r.z;
         cursor += (uint32_t)__popcll(m);
     };
     // Four full chunks per round: the reads of the groups the earlier rounds completed, then the four chunks' arithmetic
@@ -720,8 +752,6 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
         P4 r0 = w1_load(nd, 0 * kWave + lane), r1 = w1_load(nd, 1 * kWave + lane), r2 = w1_load(nd, 2 * kWave + lane), r3 = w1_load(nd, 3 * kWave + lane);
         const uint32_t lastfull = (nfull - 1u) * kWave;
         auto round = [&]() __attribute__((always_inline)) {
-            const uint32_t lim_ = cursor & ~3u;
-            prefetch();
             // (the reloads clamp to the last full chunk: loads past it would be wasted, never wrong)
             const uint32_t b4 = (c + 4) * kWave, b5 = b4 + kWave, b6 = b5 + kWave, b7 = b6 + kWave;
             __builtin_amdgcn_sched_barrier(0);
@@ -729,7 +759,7 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
             step(r1, c + 1, yes()); r1 = w1_load(nd, (b5 < lastfull ? b5 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
             step(r2, c + 2, yes()); r2 = w1_load(nd, (b6 < lastfull ? b6 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
             step(r3, c + 3, yes()); r3 = w1_load(nd, (b7 < lastfull ? b7 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
-            drain(lim_);
+            ch.consume(rowp, cursor >> 6);                            // the slots this round completed
             c += 4;
         };
         round();
@@ -737,26 +767,15 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
     }
     for (; c < nfull; ++c) {                                       // up to three full chunks left
         const P4 r = w1_load(nd, c * kWave + lane);
-        const uint32_t lim_ = cursor & ~3u; prefetch(); step(r, c, yes()); drain(lim_);
+        step(r, c, yes()); ch.consume(rowp, cursor >> 6);
     }
     if (nfull * kWave < n) {                                       // the partial chunk
         const uint32_t i = nfull * kWave + lane;
         const P4 r = w1_load(nd, i < n ? i : n - 1u);
-        const uint32_t lim_ = cursor & ~3u; prefetch(); step(r, nfull, no()); drain(lim_);
+        step(r, nfull, no()); ch.consume(rowp, cursor >> 6);
     }
-    // what the last chunk left: the complete groups, then the last 1..3 addends padded with -0.0f (the exact identity)
-    {
-        const uint32_t lim = cursor & ~3u;
-        prefetch(); drain(lim);
-        if (cursor > lim) {
-            if (lane < 12) {                                       // entries cursor .. lim+3 of the three rows
-                const uint32_t e = cursor + ((uint32_t)lane & 3u);
-                if (e < lim + 4u) ring[(lane >> 2) * kFRow + (e & (uint32_t)(kFR - 1))] = -0.0f;
-            }
-            const v4f t = rd(lim);
-            RPW_CHAIN4(acc, t)
-        }
-    }
+    ch.finish(ring, rowp, cursor, lane);
+    const float acc = ch.acc;
     FusedOut o;
     o.count = cursor;
     o.changed = ballot64(changed) != 0ull ? 1u : 0u;
@@ -948,6 +967,309 @@ __device__ __attribute__((noinline)) Sums6 w1_chain_sweep(NodeRef nd_in, uint32_
     return out;
 }
 
+// ==========================================================================================
+// TWO-WAVE FORM of the passes (patch_fit kernel with a helper wave). A lone wave pays ~4.7 cycles for every vector
+// instruction it executes besides the chain's adds, wherever it stands (tools/microbench_fill.hip: nothing but LDS,
+// scalar and memory instructions rides in a dependent add's shadow); a patch's latency is the chain's 8.2 cycles per
+// addend PLUS all the arithmetic that feeds it. Here that arithmetic moves to a second wave:
+//   wave 0 (chain wave): everything as in the single-wave form, except that in the two chained passes it only reads the
+//                        ring and adds;
+//   wave 1 (helper):     parked at a barrier; for a chained pass it receives a command (LDS) and plays the feeding half --
+//                        loads, addends, ring writes (sweep), or loads, predicate, mask bytes, index list, ring writes
+//                        (fused pass) -- one step ahead of the chain, with ONE s_barrier per step (64 addends of a
+//                        sweep, two chunks of a fused pass). The feeding half needs ~40 vector instructions where the
+//                        chain needs 64 x 8.2 cycles, so the chain never waits (round 1's producer needed ~170).
+// Both halves execute the same number of barriers by construction (it depends on the element count only).
+// ==========================================================================================
+enum { kCmdExit = 0, kCmdSweep = 1, kCmdFused = 2 };
+constexpr int kFusedRoundChunks = 2;     // two chunks per round: at most 3 + 128 + 128 addends wait in the 512-entry ring
+
+__device__ __forceinline__ void w2_barrier() { __syncthreads(); }
+// The per-step rendezvous of the two waves: LDS traffic only. (__syncthreads() also waits for vmcnt(0): the helper's
+// global loads, requested four chunks / three slots ahead, would be drained at every step and every step would pay a
+// full memory round trip -- measured: 12 cycles per point whatever the two halves did.)
+__device__ __forceinline__ void w2_step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// feeding half of a chain sweep: slot s is produced in step s; the chain adds slot s - 2 meanwhile and has prefetched s - 1
+template <int MODE, int IW>
+__device__ __forceinline__ void w2_sweep_feed(const NodeRef& nd, uint32_t count, const SweepPrm& prm, lds_f32* ring, int lane)
+{
+    constexpr int K = SweepRows<MODE>::K;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) const char g_cchar;
+    g_cchar* il = reinterpret_cast<g_cchar*>(nd.il);
+    const uint32_t nslots = (count + kWave - 1) / kWave;
+    const uint32_t last = count - 1u;
+    auto index_of = [&](uint32_t u) -> uint32_t {
+        const uint32_t j = u * kWave + lane, jc = j < last ? j : last;
+        return IW ? il_load<(IW ? IW : 4)>(il, jc) : jc;
+    };
+    auto point_of = [&](uint32_t idx) -> X3 {
+        X3 q; q.x = ldg_f32(nd.x, idx); q.y = ldg_f32(nd.y, idx);
+        q.z = (MODE == kSweepXYZ || MODE == kSweepCov || MODE == kSweepDist) ? ldg_f32(nd.z, idx) : 0.0f;
+        return q;
+    };
+    // indices two slots ahead of the point loads, points three slots ahead of their addends
+    uint32_t i3 = index_of(3), i4 = index_of(4);
+    X3 p0 = point_of(index_of(0)), p1 = point_of(index_of(1)), p2 = point_of(index_of(2));
+    for (uint32_t s = 0; s < nslots + 2u; ++s) {
+        if (s < nslots) {
+            float v[6];
+            const X3 q = p0;
+            if (MODE == kSweepCov) {
+                const f2 dxy = f2{q.x, q.y} - f2{prm.a, prm.b};
+                const float dz = q.z - prm.c;
+                const f2 a = dxy * f2{dxy.x, dxy.x};            // dx*dx, dy*dx
+                const f2 b = f2{dxy.y, dz} * f2{dxy.y, dxy.x};  // dy*dy, dz*dx
+                const f2 c = f2{dz, dz} * f2{dxy.y, dz};        // dz*dy, dz*dz
+                v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+            } else if (MODE == kSweepXYZ) { v[0] = q.x; v[1] = q.y; v[2] = q.z; }
+            else if (MODE == kSweepDist)  { v[0] = plane_dist(q.x, q.y, q.z, prm.a, prm.b, prm.c, prm.d, prm.e, prm.f); }
+            else if (MODE == kSweepRange) { v[0] = sqrt_rn(q.x * q.x + q.y * q.y); }
+            else if (MODE == kSweepXY)    { v[0] = q.x; v[1] = q.y; }
+            else { const float dx = q.x - prm.a, dy = q.y - prm.b; v[0] = dx * dx; v[1] = dy * dy; }
+            lds_f32* dst = ring + (s % (uint32_t)kW1Ring) * kSlotFloats + lane;
+            const bool live = s * kWave + lane < count;           // columns past the end: -0.0f, the exact additive identity
+#pragma unroll
+            for (int k = 0; k < K; ++k) dst[k * kLdw] = live ? v[k] : -0.0f;
+            p0 = p1; p1 = p2; p2 = point_of(i3); i3 = i4; i4 = index_of(s + 5);
+        }
+        w2_step_barrier();
+    }
+}
+
+// chain half of a chain sweep: K sequential sums, accumulator k in lane k; the same steps and barriers as w2_sweep_feed
+__device__ __forceinline__ float w2_sweep_chain(uint32_t count, int K, lds_f32* ring, int lane)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4f lds_f4;
+    const uint32_t nslots = (count + kWave - 1) / kWave;
+    const int row = lane < K ? lane : K - 1;
+    const lds_f32* rowp = ring + row * kLdw;
+    float acc = 0.0f;                                              // Zero(), then += in element order
+    v4f A[8], B[8];
+    w2_step_barrier();                                                  // step 0: slot 0 is being produced
+#pragma unroll
+    for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const lds_f4*>(rowp + 4 * q);      // first half of slot 0
+    w2_step_barrier();                                                  // step 1: slot 1 is being produced
+#define RPW_W2_SLOT(RS) {                                                                                   \
+        const lds_f32* cur = rowp + (RS) * kSlotFloats + 32;                                                \
+        const lds_f32* nxt = rowp + (((RS) + 1) % kW1Ring) * kSlotFloats;                                   \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) { B[q] = *reinterpret_cast<const lds_f4*>(cur + 4 * q); RPW_CHAIN4(acc, A[q]) __builtin_amdgcn_sched_barrier(0); } \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) { A[q] = *reinterpret_cast<const lds_f4*>(nxt + 4 * q); RPW_CHAIN4(acc, B[q]) __builtin_amdgcn_sched_barrier(0); } \
+        w2_step_barrier();                                                                                       \
+    }
+    for (uint32_t t = 0; t < nslots; t += 3) {                     // step t + 2: slot t is added, slot t + 2 is being produced
+        RPW_W2_SLOT(0)
+        if (t + 1 >= nslots) break;
+        RPW_W2_SLOT(1)
+        if (t + 2 >= nslots) break;
+        RPW_W2_SLOT(2)
+    }
+#undef RPW_W2_SLOT
+    return acc;
+}
+
+// rounds of the fused pass: R rounds of kFusedRoundChunks full chunks, then single full chunks, then the partial chunk
+__device__ __forceinline__ uint32_t w2_fused_rounds(uint32_t n)
+{
+    const uint32_t nfull = n / kWave;
+    return nfull / kFusedRoundChunks + nfull % kFusedRoundChunks + ((nfull * kWave < n) ? 1u : 0u);
+}
+
+// feeding half of the fused pass: predicate, mask byte, index list, centroid addends into the ring; after every round the
+// number of inliers so far is published, then the round's barrier
+template <int MODE, int IW>
+__device__ __forceinline__ void w2_fused_feed(const NodeRef& nd, const MaskPrm& prm, lds_f32* ring, uint32_t* fcur, uint32_t* fflags, int lane)
+{
+    typedef __attribute__((address_space(1))) char g_char;
+    g_char* il = reinterpret_cast<g_char*>(nd.il);
+    const uint32_t n = nd.n;
+    const uint32_t nfull = n / kWave;
+    uint32_t cursor = 0, round = 0;
+    bool changed = false, differs_prev = false;
+    auto step = [&](const P4& r, uint32_t c, auto full) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full)::value;
+        const uint32_t i = c * kWave + lane;
+        const bool ok = FULL || i < n;
+        bool in;
+        if (MODE == kMaskPlane) {
+            const float d = plane_dist(r.x, r.y, r.z, prm.cx, prm.cy, prm.cz, prm.nx, prm.ny, prm.nz);
+            in = d < prm.thr;
+            const bool old = r.m & 1u, prev = (r.m >> 1) & 1u;
+            changed |= ok && (in != old);
+            differs_prev |= ok && (in != prev);
+            const uint8_t nb = (uint8_t)((in ? 1u : 0u) | ((r.m & 0x7fu) << 1));
+            if (FULL) nd.m[i] = nb; else if (ok) nd.m[i] = nb;
+        } else {
+            in = r.z < prm.thr;
+            if (FULL) nd.m[i] = in ? 1 : 0; else if (ok) nd.m[i] = in ? 1 : 0;
+        }
+        in = in && ok;
+        const unsigned long long m = ballot64(in);
+        const uint32_t p = cursor + (uint32_t)mbcnt64(m);
+        const uint32_t sel = 0u - (uint32_t)in;
+        const uint32_t ip = (p & sel) | ((n - 1u) & ~sel);
+        if (FULL) il_store<IW>(il, ip, i);
+        else if (ok) il_store<IW>(il, ip, i);
+        const uint32_t lp = (fused_ring_pos(p) & sel) | ((64u + ((uint32_t)lane & 3u)) & ~sel);
+        lds_f32* w = ring + lp;
+        w[0] = r.x; w[kLdw] = r.y; w[2 * kLdw] = r.z;
+        cursor += (uint32_t)__popcll(m);
+    };
+    auto end_round = [&]() __attribute__((always_inline)) {
+        if (lane == 0) ((lds_word*)fcur)[round & 1u] = cursor;     // (an LDS store, not a flat one: flat stores count on vmcnt too)
+        ++round;
+        w2_step_barrier();
+    };
+    uint32_t c = 0;
+    if (nfull >= 4) {
+        P4 r0 = w1_load(nd, 0 * kWave + lane), r1 = w1_load(nd, 1 * kWave + lane), r2 = w1_load(nd, 2 * kWave + lane), r3 = w1_load(nd, 3 * kWave + lane);
+        const uint32_t lastfull = (nfull - 1u) * kWave;
+        // two rounds of two chunks, four register sets; the first pair of rounds is peeled out of the loop (the wait
+        // counts of a loop must also hold for the way it is entered: entered straight from the back-to-back prologue
+        // loads, its head got a vmcnt(0) and every pair of rounds paid a full memory round trip)
+        auto two_rounds = [&]() __attribute__((always_inline)) {
+            const uint32_t b4 = (c + 4) * kWave, b5 = b4 + kWave, b6 = b5 + kWave, b7 = b6 + kWave;
+            __builtin_amdgcn_sched_barrier(0);
+            step(r0, c, yes());     r0 = w1_load(nd, (b4 < lastfull ? b4 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            step(r1, c + 1, yes()); r1 = w1_load(nd, (b5 < lastfull ? b5 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            end_round();
+            step(r2, c + 2, yes()); r2 = w1_load(nd, (b6 < lastfull ? b6 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            step(r3, c + 3, yes()); r3 = w1_load(nd, (b7 < lastfull ? b7 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            end_round();
+            c += 4;
+        };
+        two_rounds();
+        while (c + 4 <= nfull) two_rounds();
+    }
+    // what is left: 0..3 full chunks, in rounds of two, then of one
+    for (; c + 2 <= nfull; c += 2) {
+        const P4 ra = w1_load(nd, c * kWave + lane), rb = w1_load(nd, (c + 1) * kWave + lane);
+        step(ra, c, yes()); step(rb, c + 1, yes());
+        end_round();
+    }
+    for (; c < nfull; ++c) {
+        const P4 r = w1_load(nd, c * kWave + lane);
+        step(r, c, yes());
+        end_round();
+    }
+    if (nfull * kWave < n) {
+        const uint32_t i = nfull * kWave + lane;
+        const P4 r = w1_load(nd, i < n ? i : n - 1u);
+        step(r, nfull, no());
+        end_round();
+    }
+    const bool ch = ballot64(changed) != 0ull, df = ballot64(differs_prev) != 0ull;
+    if (lane == 0) { ((lds_word*)fflags)[0] = ch ? 1u : 0u; ((lds_word*)fflags)[1] = df ? 1u : 0u; }
+    w2_barrier();                                                  // the final barrier, a full one: the mask bytes and the index list are written
+}
+
+// chain half of the fused pass: round r adds the slots the rounds before it completed; R + 1 barriers like the feeding half.
+// (While round r is written, the slots being read start at most 4 slots behind the write position: 8 slots are enough.)
+__device__ __forceinline__ FusedOut w2_fused_chain(uint32_t n, lds_f32* ring, const uint32_t* fcur, const uint32_t* fflags, int lane)
+{
+    const uint32_t R = w2_fused_rounds(n);
+    FusedChain ch;
+    const int row = lane < 3 ? lane : 2;
+    const lds_f32* rowp = ring + row * kLdw;
+    const lds_word* lcur = (const lds_word*)fcur;
+    w2_step_barrier();                                             // round 0 is being produced
+    for (uint32_t r = 1; r < R; ++r) {                             // round r is being produced; rounds < r are complete
+        ch.consume(rowp, uni(lcur[(r - 1u) & 1u]) >> 6);
+        w2_step_barrier();
+    }
+    const uint32_t cursor = uni(lcur[(R - 1u) & 1u]);
+    ch.consume(rowp, cursor >> 6);                                 // the helper is finishing (flags, final barrier)
+    w2_barrier();
+    ch.finish(ring, rowp, cursor, lane);                           // everything is produced: the last slot, padded
+    FusedOut o;
+    o.count = cursor; o.changed = ((const lds_word*)fflags)[0]; o.differs_prev = ((const lds_word*)fflags)[1];
+    o.sx = __shfl(ch.acc, 0); o.sy = __shfl(ch.acc, 1); o.sz = __shfl(ch.acc, 2);
+    return o;
+}
+
+// The helper wave: waits for commands, plays the feeding half of the pass, until it is told to leave.
+__device__ __attribute__((noinline)) void w2_helper_loop(Fit1Shared* shp)
+{
+    const int lane = threadIdx.x & 63;
+    lds_f32* ring = (lds_f32*)shp->ring;
+    for (;;) {
+        w2_barrier();                                              // a command is there
+        const uint32_t* c = shp->cmd;
+        const uint32_t op = uni(c[0]);
+        if (op == (uint32_t)kCmdExit) break;
+        const uint32_t mode = uni(c[1]), count = uni(c[2]);
+        NodeRef nd;
+        nd.x = (g_cf32*)(((unsigned long long)uni(c[5]) << 32) | uni(c[4]));
+        nd.y = (g_cf32*)(((unsigned long long)uni(c[7]) << 32) | uni(c[6]));
+        nd.z = (g_cf32*)(((unsigned long long)uni(c[9]) << 32) | uni(c[8]));
+        nd.m = (g_u8*)(((unsigned long long)uni(c[11]) << 32) | uni(c[10]));
+        nd.il = (g_u32*)(((unsigned long long)uni(c[13]) << 32) | uni(c[12]));
+        nd.n = uni(c[3]);
+        const bool narrow = nd.n <= 65536u;
+        if (op == (uint32_t)kCmdSweep) {
+            SweepPrm prm; prm.a = uni(__uint_as_float(c[14])); prm.b = uni(__uint_as_float(c[15])); prm.c = uni(__uint_as_float(c[16]));
+            prm.d = uni(__uint_as_float(c[17])); prm.e = uni(__uint_as_float(c[18])); prm.f = uni(__uint_as_float(c[19]));
+            switch (mode) {
+            case kSweepCov:   if (narrow) w2_sweep_feed<kSweepCov, 2>(nd, count, prm, ring, lane); else w2_sweep_feed<kSweepCov, 4>(nd, count, prm, ring, lane); break;
+            case kSweepXYZ:   if (narrow) w2_sweep_feed<kSweepXYZ, 2>(nd, count, prm, ring, lane); else w2_sweep_feed<kSweepXYZ, 4>(nd, count, prm, ring, lane); break;
+            case kSweepDist:  if (narrow) w2_sweep_feed<kSweepDist, 2>(nd, count, prm, ring, lane); else w2_sweep_feed<kSweepDist, 4>(nd, count, prm, ring, lane); break;
+            case kSweepRange: w2_sweep_feed<kSweepRange, 0>(nd, count, prm, ring, lane); break;
+            case kSweepXY:    w2_sweep_feed<kSweepXY, 0>(nd, count, prm, ring, lane); break;
+            default:          w2_sweep_feed<kSweepVarXY, 0>(nd, count, prm, ring, lane); break;
+            }
+        } else {
+            MaskPrm mp; mp.cx = uni(__uint_as_float(c[14])); mp.cy = uni(__uint_as_float(c[15])); mp.cz = uni(__uint_as_float(c[16]));
+            mp.nx = uni(__uint_as_float(c[17])); mp.ny = uni(__uint_as_float(c[18])); mp.nz = uni(__uint_as_float(c[19])); mp.thr = uni(__uint_as_float(c[20]));
+            if (mode == (uint32_t)kMaskPlane) { if (narrow) w2_fused_feed<kMaskPlane, 2>(nd, mp, ring, shp->fcur, shp->fflags, lane); else w2_fused_feed<kMaskPlane, 4>(nd, mp, ring, shp->fcur, shp->fflags, lane); }
+            else { if (narrow) w2_fused_feed<kMaskSeed, 2>(nd, mp, ring, shp->fcur, shp->fflags, lane); else w2_fused_feed<kMaskSeed, 4>(nd, mp, ring, shp->fcur, shp->fflags, lane); }
+        }
+    }
+}
+
+// chain-wave side: hand the helper a command, then run the chain half. (The node's pointers travel through LDS.)
+__device__ __forceinline__ void w2_post(Fit1Shared* shp, int lane, uint32_t op, uint32_t mode, uint32_t count, const NodeRef& nd, const float* f7)
+{
+    if (lane == 0) {
+        uint32_t* c = shp->cmd;
+        c[0] = op; c[1] = mode; c[2] = count; c[3] = nd.n;
+        const unsigned long long px = (unsigned long long)nd.x, py = (unsigned long long)nd.y, pz = (unsigned long long)nd.z,
+                                 pm = (unsigned long long)nd.m, pi = (unsigned long long)nd.il;
+        c[4] = (uint32_t)px; c[5] = (uint32_t)(px >> 32); c[6] = (uint32_t)py; c[7] = (uint32_t)(py >> 32);
+        c[8] = (uint32_t)pz; c[9] = (uint32_t)(pz >> 32); c[10] = (uint32_t)pm; c[11] = (uint32_t)(pm >> 32);
+        c[12] = (uint32_t)pi; c[13] = (uint32_t)(pi >> 32);
+        for (int k = 0; k < 7; ++k) c[14 + k] = __float_as_uint(f7[k]);
+    }
+    w2_barrier();                                                  // (waits for the stores above: the helper reads them behind it)
+}
+
+__device__ __attribute__((noinline)) Sums6 w2_chain_sweep(Fit1Shared* shp, NodeRef nd, uint32_t count, int mode, SweepPrm prm)
+{
+    const int lane = threadIdx.x & 63;
+    Sums6 out;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out.v[k] = 0.0f;
+    count = uni(count);
+    if (count == 0) return out;
+    const float f7[7] = {prm.a, prm.b, prm.c, prm.d, prm.e, prm.f, 0.0f};
+    const int m = (int)uni((uint32_t)mode);
+    w2_post(shp, lane, kCmdSweep, (uint32_t)m, count, nd, f7);
+    const int K = m == kSweepCov ? 6 : (m == kSweepXYZ ? 3 : ((m == kSweepXY || m == kSweepVarXY) ? 2 : 1));
+    const float acc = w2_sweep_chain(count, K, (lds_f32*)shp->ring, lane);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out.v[k] = __shfl(acc, k);
+    return out;
+}
+
+__device__ __attribute__((noinline)) FusedOut w2_fused_pass(Fit1Shared* shp, NodeRef nd, int mode, MaskPrm prm)
+{
+    const int lane = threadIdx.x & 63;
+    const float f7[7] = {prm.cx, prm.cy, prm.cz, prm.nx, prm.ny, prm.nz, prm.thr};
+    w2_post(shp, lane, kCmdFused, uni((uint32_t)mode), 0u, nd, f7);
+    return w2_fused_chain(uni(nd.n), (lds_f32*)shp->ring, shp->fcur, shp->fflags, lane);
+}
+
 // exact order statistic, single wave (see select_rank)
 __device__ __attribute__((noinline)) float w1_select_rank(W1 cx, uint32_t s, uint32_t n, int axis, uint32_t k)
 {
@@ -956,12 +1278,12 @@ __device__ __attribute__((noinline)) float w1_select_rank(W1 cx, uint32_t s, uin
     uint32_t prefix = 0, pmask = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int j = cx.lane; j < 256; j += kWave) hist[j] = 0;
-        __syncthreads();
+        wave_sync();
         for (uint32_t i = cx.lane; i < n; i += kWave) {
             const uint32_t key = float_key(src[i]);
             if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
-        __syncthreads();
+        wave_sync();
         const uint32_t h0 = hist[4 * cx.lane], h1 = hist[4 * cx.lane + 1], h2 = hist[4 * cx.lane + 2], h3 = hist[4 * cx.lane + 3];
         const uint32_t tot = h0 + h1 + h2 + h3;
         const uint32_t incl = wave_incl_scan(tot);
@@ -980,7 +1302,7 @@ __device__ __attribute__((noinline)) float w1_select_rank(W1 cx, uint32_t s, uin
         bin = __shfl(bin, owner); before = __shfl(before, owner);
         prefix |= bin << shift; pmask |= 255u << shift;
         k -= before;
-        __syncthreads();
+        wave_sync();
     }
     return key_float(prefix);
 }
@@ -1032,7 +1354,6 @@ __device__ __attribute__((noinline)) N3 w1_normal(float a00, float a10, float a1
 // Gather prologue (see patch_fit_kernel): assembles the patch's contiguous slots from its runs in the tile-sorted
 // records and returns the bounding box of the whole patch.
 struct Box6 { float v[6]; };
-typedef __attribute__((address_space(3))) uint32_t lds_word;
 struct GatherArgs {
     const uint32_t *goff, *gdir;       // this patch's column of the run-length / run-start directories, first tile of the frame
     const float4* tp;
@@ -1057,7 +1378,7 @@ __device__ __attribute__((noinline)) Box6 w1_gather(GatherArgs g, lds_word* toff
         uint32_t run = incl - sum;
         for (uint32_t t = ta; t < tb; ++t) { const uint32_t len = toff[t]; toff[t] = run; run += len; }
     }
-    __syncthreads();
+    wave_sync();
     const uint32_t rel0 = in_lds ? 0u : g.begin - g.fo;
     uint32_t top = 1; while (top * 2u < nt) top *= 2u;
     constexpr int kGatherWide = 8;
@@ -1107,11 +1428,18 @@ __device__ __attribute__((noinline)) Box6 w1_gather(GatherArgs g, lds_word* toff
     return b;
 }
 
-__global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p)
+// W = 1: one wave per patch (16 patches per CU: the throughput form). W = 2: chain wave + helper wave (8 patches per CU:
+// the latency form, about half the time per patch); the host picks by the number of patches in the launch.
+template <int W>
+__global__ __launch_bounds__(kFit1Threads * W, 4) void patch_fit1_kernel(DevParams p)
 {
     __shared__ Fit1Shared sh;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
 #define W1_PH(IDX, CNT, ...) { __VA_ARGS__; }
+    // the passes that run a chain: single-wave form, or chain half here + feeding half on the helper wave
+#define W_SWEEP(ND, M, MODE, INDEXED, PRM) (W == 2 ? w2_chain_sweep(&sh, ND, M, MODE, PRM) : w1_chain_sweep(ND, M, MODE, INDEXED, PRM, ring))
+#define W_FUSED(ND, MODE, PRM) (W == 2 ? w2_fused_pass(&sh, ND, MODE, PRM) : w1_fused_pass(ND, MODE, PRM, ring))
+#define W_LEAVE() { if (W == 2) { if (lane == 0) sh.cmd[0] = (uint32_t)kCmdExit; w2_barrier(); } }
 
     // ---- block -> patch, largest size bucket first --------------------------------------------
     uint32_t linear;
@@ -1124,6 +1452,10 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         const int l = __ffsll((long long)bm) - 1;
         const uint32_t before = __shfl(incl - cnt, l);
         linear = p.bucket_list[(size_t)(kBuckets - 1 - l) * p.list_stride + (blockIdx.x - before)];
+    }
+    if (W == 2 && threadIdx.x >= 64) {                 // the helper wave: serves the chain wave until told to leave
+        w2_helper_loop(&sh);
+        return;
     }
     const int frame = (int)(linear / (uint32_t)p.P), patch = (int)(linear % (uint32_t)p.P);
     const PatchDesc pd = p.patches[linear];
@@ -1146,14 +1478,15 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         W1_PH(0, pd.n, b = w1_gather(g, (lds_word*)sh.dir.toff, (lds_word*)sh.dir.tsrc))
 #pragma unroll
         for (int k = 0; k < 6; ++k) rootbox[k] = b.v[k];
-        __syncthreads();                               // the directory's LDS becomes the ring; the wave's own stores are ordered
+        wave_sync();                               // the directory's LDS becomes the ring; the wave's own stores are ordered
     }
 
-    if (p.gather_only) return;                         // diagnostic: the binning pass ends here (per-patch compaction done)
+    if (p.gather_only) { W_LEAVE() return; }            // diagnostic: the binning pass ends here (per-patch compaction done)
 
     // zone < 3: the reference returns {{}, cleaned} before looking at any patch (recursive_patchwork.cpp:339-341)
     if (p.stats[frame].n_zone < 3u) {
         for (uint32_t i = lane; i < pd.n; i += kFit1Threads) p.labels[fo + p.sidx[pd.begin + i]] = RPW_LABEL_NONGROUND;
+        W_LEAVE()
         return;
     }
 
@@ -1165,7 +1498,7 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         NodeRef root; root.x = (g_cf32*)(p.sx + cx.base); root.y = (g_cf32*)(p.sy + cx.base); root.z = (g_cf32*)(p.sz + cx.base);
         root.m = (g_u8*)(p.mask + cx.base); root.il = (g_u32*)(cx.il + cx.base); root.n = pd.n;
         Sums6 sum;
-        W1_PH(1, pd.n, sum = w1_chain_sweep(root, pd.n, kSweepRange, 0, no_prm, ring))
+        W1_PH(1, pd.n, sum = W_SWEEP(root, pd.n, kSweepRange, 0, no_prm))
         cx.addends += pd.n;
         mean_dist = sum.v[0] / (float)pd.n;
     }
@@ -1178,13 +1511,13 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
     int sp = 0;
     if (lane == 0) { stk[0] = 0; stk[1] = pd.n; stk[2] = 0; }
     sp = 1;
-    __syncthreads();
+    wave_sync();
 
     while (sp > 0) {
         --sp;
         const uint32_t s = stk[3 * sp], n = stk[3 * sp + 1];
         const int depth = (int)stk[3 * sp + 2];
-        __syncthreads();
+        wave_sync();
         pa.nodes++;
         if ((uint32_t)depth > pa.maxdepth) pa.maxdepth = (uint32_t)depth;
         const float* gx = p.sx + cx.base + s;
@@ -1240,7 +1573,7 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         uint32_t count;
         {   // seed mask + index list + centroid sums of the seeds, one pass
             FusedOut fo_;
-            W1_PH(2, n, fo_ = w1_fused_pass(nd, kMaskSeed, mp, ring))
+            W1_PH(2, n, fo_ = W_FUSED(nd, kMaskSeed, mp))
             count = fo_.count; cs[0] = fo_.sx; cs[1] = fo_.sy; cs[2] = fo_.sz;
             cx.addends += count;
         }
@@ -1257,13 +1590,13 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
                 else { gl[0] = a; gl[1] = b; gl[2] = c; }
             }
             count = 3;
-            __syncthreads();                           // index list and mask bytes written by this wave: drain before the reads
+            wave_sync();                           // index list and mask bytes written by this wave: drain before the reads
             Sums6 r;
-            W1_PH(3, 3, r = w1_chain_sweep(nd, 3, kSweepXYZ, 1, no_prm, ring))
+            W1_PH(3, 3, r = W_SWEEP(nd, 3, kSweepXYZ, 1, no_prm))
             cx.addends += 3;
             cs[0] = r.v[0]; cs[1] = r.v[1]; cs[2] = r.v[2];
         }
-        __syncthreads();
+        wave_sync();
 
         // ---- iterative refit (recursive_patchwork.cpp:186-217) ------------------------------------
         PlaneD pl; pl.cx = pl.cy = pl.cz = 0.0f; pl.nx = 0.0f; pl.ny = 0.0f; pl.nz = 1.0f; pl.residual = 3.402823466e+38f;
@@ -1271,7 +1604,7 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
             const float fm = (float)m;
             SweepPrm c; c.a = cs[0] / fm; c.b = cs[1] / fm; c.c = cs[2] / fm; c.d = c.e = c.f = 0.0f;
             Sums6 cv;
-            W1_PH(4, m, cv = w1_chain_sweep(nd, m, kSweepCov, 1, c, ring))
+            W1_PH(4, m, cv = W_SWEEP(nd, m, kSweepCov, 1, c))
             cx.addends += m;
             const float fm1 = (float)(m - 1);
             pl.cx = c.a; pl.cy = c.b; pl.cz = c.c;
@@ -1282,7 +1615,7 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         auto residual_of = [&](uint32_t m) -> float {   // sum of |d| over the index list / m (recursive_patchwork.cpp:98-104)
             SweepPrm q; q.a = pl.cx; q.b = pl.cy; q.c = pl.cz; q.d = pl.nx; q.e = pl.ny; q.f = pl.nz;
             Sums6 r;
-            W1_PH(6, m, r = w1_chain_sweep(nd, m, kSweepDist, 1, q, ring))
+            W1_PH(6, m, r = W_SWEEP(nd, m, kSweepDist, 1, q))
             cx.addends += m;
             return r.v[0] / (float)m;
         };
@@ -1296,11 +1629,11 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
             ++iters;
             mp.cx = pl.cx; mp.cy = pl.cy; mp.cz = pl.cz; mp.nx = pl.nx; mp.ny = pl.ny; mp.nz = pl.nz; mp.thr = threshold;
             FusedOut mo;                                         // new mask + its index list + its centroid sums
-            W1_PH(2, n, mo = w1_fused_pass(nd, kMaskPlane, mp, ring))
+            W1_PH(2, n, mo = W_FUSED(nd, kMaskPlane, mp))
             const uint32_t newcount = mo.count;
             cx.addends += newcount;
             const bool any_changed = mo.changed != 0, any_differs_prev = mo.differs_prev != 0;
-            __syncthreads();
+            wave_sync();
             if (!any_changed) {                                  // new_mask == ground_mask: converged
                 pl.residual = residual_of(count);
                 have_plane = true; have_residual = true;
@@ -1332,7 +1665,7 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
             if (!have_residual) {
                 if (!list_is_final) {                            // rebuild the list from the older mask (bit 1)
                     (void)w1_mask_pass(nd, kMaskOlder, mp);
-                    __syncthreads();
+                    wave_sync();
                 }
                 pl.residual = residual_of(count);
             }
@@ -1342,10 +1675,10 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         const float split_threshold = cfg.th_dist * (1.0f + 1.5f * (float)depth);
         const uint32_t min_patch = 50u + 10u * (uint32_t)depth;
         if (pl.residual > split_threshold && depth < cfg.max_split_depth && n >= min_patch) {
-            const Sums6 m2 = w1_chain_sweep(nd, n, kSweepXY, 0, no_prm, ring);
+            const Sums6 m2 = W_SWEEP(nd, n, kSweepXY, 0, no_prm);
             const float fn = (float)n;
             SweepPrm mean = no_prm; mean.a = m2.v[0] / fn; mean.b = m2.v[1] / fn;
-            const Sums6 v2 = w1_chain_sweep(nd, n, kSweepVarXY, 0, mean, ring);
+            const Sums6 v2 = W_SWEEP(nd, n, kSweepVarXY, 0, mean);
             cx.addends += 2ull * n;
             const float var_x = v2.v[0] / fn, var_y = v2.v[1] / fn;
             const int axis = (var_x > var_y) ? 0 : 1;
@@ -1370,12 +1703,12 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
                 }
                 lo += (uint32_t)__popcll(ml); ro += (uint32_t)__popcll(mr);
             }
-            __syncthreads();
+            wave_sync();
             for (uint32_t i = lane; i < n; i += kFit1Threads) {
                 const uint32_t g = cx.base + s + i;
                 p.sx[g] = p.ax[g]; p.sy[g] = p.ay[g]; p.sz[g] = p.az[g];
             }
-            __syncthreads();
+            wave_sync();
             permuted = true;
             pa.splits++;
             pa.iters += (unsigned long long)iters;
@@ -1389,7 +1722,7 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
                 stk[3 * (sp + 1)] = sm_s; stk[3 * (sp + 1) + 1] = sm_n; stk[3 * (sp + 1) + 2] = (uint32_t)(depth + 1);
             }
             sp += 2;
-            __syncthreads();
+            wave_sync();
             continue;
         }
 
@@ -1420,6 +1753,7 @@ __global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p
         emit_node(p, lane, frame, patch, depth, s, n, RPW_NODE_FIT, iters, count, -1, 0.0f, &pl);
     }
 
+    W_LEAVE()
     if (lane == 0) {
         rpw_frame_stats* st = p.stats + frame;
         atomicAdd((unsigned long long*)&st->chain_addends, cx.addends);
@@ -1454,10 +1788,13 @@ __global__ void debug_eig3_kernel(const float* cov, float* nrm, uint32_t n)
 // micro-benchmark of the two loops patch_fit1 lives in (test hook rpw_debug_loop_bench): every block runs `reps`
 // chain sweeps (what = sweep mode) or mask passes (what = 16 + mask mode) over its own synthetic node of n slots
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kFit1Threads, 4) void w1_loop_bench_kernel(const float* sx, const float* sy, const float* sz, uint8_t* mask,
-                                                                        uint32_t* il, uint32_t n, uint32_t count, int what, int reps, float* out)
+template <int W>
+__global__ __launch_bounds__(kFit1Threads * W, 4) void w1_loop_bench_kernel(const float* sx, const float* sy, const float* sz, uint8_t* mask,
+                                                                            uint32_t* il, uint32_t n, uint32_t count, int what, int reps, float* out)
 {
     __shared__ Fit1Shared sh;
+    if (W == 2 && threadIdx.x >= 64) { w2_helper_loop(&sh); return; }
+    const int lane = threadIdx.x & 63;
     lds_f32* ring = (lds_f32*)sh.ring;
     const size_t base = (size_t)blockIdx.x * n;
     NodeRef nd; nd.x = (g_cf32*)(sx + base); nd.y = (g_cf32*)(sy + base); nd.z = (g_cf32*)(sz + base);
@@ -1466,21 +1803,18 @@ __global__ __launch_bounds__(kFit1Threads, 4) void w1_loop_bench_kernel(const fl
     for (int r = 0; r < reps; ++r) {
         if (what < 16) {
             SweepPrm prm; prm.a = 0.25f + acc * 0.0f; prm.b = -0.5f; prm.c = 0.125f; prm.d = 0.0f; prm.e = 0.0f; prm.f = 1.0f;
-            const Sums6 v = w1_chain_sweep(nd, count, what, 1, prm, ring);
+            const Sums6 v = W == 2 ? w2_chain_sweep(&sh, nd, count, what, prm) : w1_chain_sweep(nd, count, what, 1, prm, ring);
             acc += v.v[0];
         } else {
             MaskPrm mp; mp.cx = 0.0f; mp.cy = 0.0f; mp.cz = acc * 0.0f; mp.nx = 0.0f; mp.ny = 0.0f; mp.nz = 1.0f; mp.thr = 0.6f;
             if (what == 18) { const MaskOut o = w1_mask_pass(nd, kMaskOlder, mp); acc += (float)o.count; }
-            else { const FusedOut o = w1_fused_pass(nd, what - 16, mp, ring); acc += (float)o.count + o.sx * 0.0f; }
+            else { const FusedOut o = W == 2 ? w2_fused_pass(&sh, nd, what - 16, mp) : w1_fused_pass(nd, what - 16, mp, ring); acc += (float)o.count + o.sx * 0.0f; }
         }
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+    if (W == 2) { if (lane == 0) sh.cmd[0] = (uint32_t)kCmdExit; w2_barrier(); }
+    if (lane == 0) out[blockIdx.x] = acc;
 }
 
-// ------------------------------------------------------------------------------------------
-// host-pointer pipeline helpers: a frame in a pipeline slot is processed by kernels only (no copy-engine
-// operation sits between two frames' kernels): its input is read in place from pinned host memory by bin_tile,
-// and its results are written to pinned host memory by frame_copy_out.
 // ------------------------------------------------------------------------------------------
 // per-frame result record of a batch, as four int32: ground points, non-ground points of the zone, patches, refits
 // (what the multi-GPU result gather exchanges: reference callers get exactly these counts, recursive_patchwork.cpp:421-423)
@@ -1556,7 +1890,12 @@ void launch_fit(const DevParams& p, hipStream_t s)
         const size_t per = (160u * 1024u) / (size_t)k, stat = sizeof(Fit1Shared) + 64;
         return per > stat ? ((per - stat) & ~(size_t)255) : (size_t)0;
     }();
-    hipLaunchKernelGGL(patch_fit1_kernel, dim3(grid), dim3(kFit1Threads), pad, s, p);
+    // Few patches in the launch (a frame or a few: the host-pointer path) -> the two-wave latency form; a batch that
+    // fills the chip -> the single-wave throughput form. RPW_FIT_WAVES=1|2 forces one (tests, A/B measurements).
+    static const int forced = [] { const char* e = getenv("RPW_FIT_WAVES"); return e ? atoi(e) : 0; }();
+    const bool two = forced == 2 || (forced != 1 && grid <= 8u * 256u);
+    if (two) hipLaunchKernelGGL(patch_fit1_kernel<2>, dim3(grid), dim3(2 * kFit1Threads), pad, s, p);
+    else     hipLaunchKernelGGL(patch_fit1_kernel<1>, dim3(grid), dim3(kFit1Threads), pad, s, p);
 }
 void launch_result_record(const rpw_frame_stats* stats, int32_t* out, uint32_t n_frames, hipStream_t s)
 {
@@ -1577,7 +1916,10 @@ void launch_frame_copy_out(const uint8_t* labels, uint8_t* h_labels, uint32_t n,
 void launch_loop_bench(const float* sx, const float* sy, const float* sz, uint8_t* mask, uint32_t* il, uint32_t n, uint32_t count,
                        int what, int reps, uint32_t blocks, float* out, hipStream_t s)
 {
-    hipLaunchKernelGGL(w1_loop_bench_kernel, dim3(blocks), dim3(kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out);
+    const int w = what >= 32 ? 2 : 1;                 // what + 32: the same loop in the two-wave form
+    what &= 31;
+    if (w == 2) hipLaunchKernelGGL(w1_loop_bench_kernel<2>, dim3(blocks), dim3(2 * kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out);
+    else        hipLaunchKernelGGL(w1_loop_bench_kernel<1>, dim3(blocks), dim3(kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out);
 }
 void launch_debug_angles(const float* x, const float* y, float* a, uint32_t n, hipStream_t s)
 {
