@@ -272,7 +272,7 @@ rpw_status alloc_slot(rpw_handle* h, Slot* s)
     RPW_HIP(h, hipHostMalloc((void**)&s->h_in, s->h_in_bytes, hipHostMallocDefault));
     RPW_HIP(h, hipHostMalloc((void**)&s->h_labels, N, hipHostMallocDefault));
     RPW_HIP(h, hipMalloc((void**)&s->d_labels, N));
-    RPW_HIP(h, hipHostMalloc((void**)&s->h_stats, sizeof(rpw_frame_stats), hipHostMallocDefault));
+    RPW_HIP(h, hipHostMalloc((void**)&s->h_stats, sizeof(rpw_frame_stats) + 16, hipHostMallocDefault));
     return RPW_OK;
 }
 
@@ -354,7 +354,7 @@ void fill_params(rpw_handle* h, Workspace& w, DevParams& p, const void* d_xyz, u
     p.mask = w.d_mask; p.stats = w.d_stats;
     // the trace buffer belongs to the handle: only its own workspace writes it
     const bool tracing = (&w == &h->ws) && h->trace && h->d_nodes;
-    p.trace = tracing ? 1 : 0; p.nodes = tracing ? h->d_nodes : nullptr; p.node_count = w.d_ctrl + kBuckets; p.nodes_cap = tracing ? h->nodes_cap : 0;
+    p.trace = tracing ? 1 : 0; p.nodes = tracing ? h->d_nodes : nullptr; p.node_count = w.d_ctrl + kBuckets; p.work = w.d_ctrl + kBuckets + 1; p.nodes_cap = tracing ? h->nodes_cap : 0;
     p.gather_only = h->debug_gather_only;
 
 }
@@ -473,7 +473,7 @@ rpw_status enqueue_slot(rpw_handle* h, Slot* s, uint32_t n, size_t bytes, const 
     timed(h, RPW_K_BIN, st, [&] { launch_bin(p, st); });
     timed(h, RPW_K_SCAN, st, [&] { launch_scan(p, st); });
     timed(h, RPW_K_FIT, st, [&] { launch_fit(p, st); });
-    launch_frame_copy_out(s->d_labels, s->h_labels, n, want_residual ? s->d_res : nullptr, s->h_res, w.d_stats, s->h_stats, st);
+    launch_frame_copy_out(s->d_labels, s->h_labels, n, want_residual ? s->d_res : nullptr, s->h_res, w.d_stats, s->h_stats, w.d_ctrl + kBuckets + 2, st);
     RPW_HIP(h, hipGetLastError());
     RPW_HIP(h, hipEventRecord(s->done, st));
     s->pending = true; s->want_residual = want_residual; s->n = n;
@@ -574,6 +574,16 @@ rpw_status rpw_segment_batch_device(rpw_handle* h, const float* d_xyz, const uin
     return run_batch(h, h->ws, d_xyz, frame_offsets, n_frames, d_labels, d_residual, (hipStream_t)stream);
 }
 
+// patch_fit's chain-server form hands work between waves through LDS words and polls with a spin limit: a protocol error
+// ends the launch with this flag set instead of hanging the GPU. The batch's stream must have completed.
+static const char* const kFitErrorText = "patch_fit: a wave timed out waiting for the chain server (results of this batch are invalid)";
+static rpw_status check_fit_error(rpw_handle* h, Workspace& w)
+{
+    uint32_t flag = 0;
+    RPW_HIP(h, hipMemcpy(&flag, w.d_ctrl + kBuckets + 2, sizeof flag, hipMemcpyDeviceToHost));
+    return flag ? fail(h, RPW_ERR_HIP, "%s", kFitErrorText) : RPW_OK;
+}
+
 rpw_status rpw_get_batch_stats(rpw_handle* h, rpw_frame_stats* stats, uint32_t n_frames)
 {
     if (!h || !stats) return RPW_ERR_INVALID;
@@ -581,7 +591,7 @@ rpw_status rpw_get_batch_stats(rpw_handle* h, rpw_frame_stats* stats, uint32_t n
     RPW_HIP(h, hipSetDevice(h->device));
     RPW_HIP(h, hipStreamSynchronize(h->ws.last_stream));
     if (n_frames) RPW_HIP(h, hipMemcpy(stats, h->ws.d_stats, n_frames * sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
-    return RPW_OK;
+    return check_fit_error(h, h->ws);
 }
 
 rpw_status rpw_result_record_device(rpw_handle* h, int32_t* d_out, uint32_t n_frames, void* stream)
@@ -624,7 +634,7 @@ rpw_status rpw_segment(rpw_handle* h, const float* xyz, uint32_t n, uint8_t* lab
     if (n && residual) RPW_HIP(h, hipMemcpyAsync(residual, h->d_res, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
     RPW_HIP(h, hipStreamSynchronize(s));
     if (stats) RPW_HIP(h, hipMemcpy(stats, h->ws.d_stats, sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
-    return RPW_OK;
+    return check_fit_error(h, h->ws);
 }
 
 rpw_status rpw_segment_pointcloud2(rpw_handle* h, const uint8_t* data, uint32_t n, uint32_t point_step,
@@ -658,7 +668,7 @@ rpw_status rpw_segment_pointcloud2(rpw_handle* h, const uint8_t* data, uint32_t 
     if (n && residual) RPW_HIP(h, hipMemcpyAsync(residual, h->d_res, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
     RPW_HIP(h, hipStreamSynchronize(s));
     if (stats) RPW_HIP(h, hipMemcpy(stats, h->ws.d_stats, sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
-    return RPW_OK;
+    return check_fit_error(h, h->ws);
 }
 
 /* ---- host-pointer pipeline: K frames in flight, one slot each ---------------------------------------------------- */
@@ -749,6 +759,7 @@ rpw_status rpw_wait(rpw_handle* h, uint32_t slot, uint8_t* labels, float* residu
     if (s->n) std::memcpy(labels, s->h_labels, s->n);
     if (s->n && residual) std::memcpy(residual, s->h_res, (size_t)s->n * sizeof(float));
     if (stats) *stats = *s->h_stats;
+    if (*reinterpret_cast<const uint32_t*>(s->h_stats + 1)) return fail(h, RPW_ERR_HIP, "%s", kFitErrorText);
     return RPW_OK;
 }
 
@@ -810,7 +821,7 @@ rpw_status rpw_segment_fused(rpw_handle* h, const float* xyz, const uint32_t* se
     if (n && residual) RPW_HIP(h, hipMemcpyAsync(residual, h->d_res, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
     RPW_HIP(h, hipStreamSynchronize(s));
     if (stats) RPW_HIP(h, hipMemcpy(stats, h->ws.d_stats, sizeof(rpw_frame_stats), hipMemcpyDeviceToHost));
-    return RPW_OK;
+    return check_fit_error(h, h->ws);
 }
 
 rpw_status rpw_segment_batch_device_fused(rpw_handle* h, const float* d_xyz, const uint32_t* frame_offsets,
@@ -906,7 +917,7 @@ rpw_status rpw_debug_loop_bench(rpw_handle* h, int what, uint32_t n, uint32_t in
     if (!h || !ms || n == 0 || blocks == 0 || reps <= 0 || inlier_pct > 100) return RPW_ERR_INVALID;
     if ((uint64_t)n * blocks > (1ull << 28)) return fail(h, RPW_ERR_CAPACITY, "loop bench: n * blocks too large");
     const int base_what = what & 31;
-    if ((what & ~63) || !((base_what >= 0 && base_what <= 5) || (base_what >= 16 && base_what <= 18)))
+    if ((what & ~127) || (what & 96) == 96 || !((base_what >= 0 && base_what <= 5) || (base_what >= 16 && base_what <= 18)))
         return fail(h, RPW_ERR_INVALID, "loop bench: unknown loop %d", what);
     RPW_HIP(h, hipSetDevice(h->device));
     const size_t total = (size_t)n * blocks;

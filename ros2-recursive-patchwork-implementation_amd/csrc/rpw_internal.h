@@ -76,6 +76,7 @@ struct DevParams {
     rpw_frame_stats* stats;       // [F]
     rpw_node* nodes;              // trace (may be null)
     uint32_t* node_count;
+    uint32_t* work;               // [0] work counter of patch_fit's chain-server form, [1] its error flag (zeroed with the bucket counts)
     uint32_t  nodes_cap;
     int       trace;
     int       gather_only;        // diagnostic (rpw_set_debug_gather_only): patch_fit stops behind its gather prologue
@@ -86,7 +87,7 @@ void launch_scan(const DevParams& p, hipStream_t s);
 void launch_fit(const DevParams& p, hipStream_t s);
 void launch_frame_setup(uint32_t* offsets, uint32_t n, uint32_t tiles, uint32_t* ctrl, uint32_t ctrl_words, hipStream_t s);
 void launch_frame_copy_out(const uint8_t* labels, uint8_t* h_labels, uint32_t n, const float* res, float* h_res,
-                           const rpw_frame_stats* stats, rpw_frame_stats* h_stats, hipStream_t s);
+                           const rpw_frame_stats* stats, rpw_frame_stats* h_stats, const uint32_t* fit_error, hipStream_t s);
 void launch_loop_bench(const float* sx, const float* sy, const float* sz, uint8_t* mask, uint32_t* il, uint32_t n, uint32_t count,
                        int what, int reps, uint32_t blocks, float* out, hipStream_t s);
 void launch_result_record(const rpw_frame_stats* stats, int32_t* out, uint32_t n_frames, hipStream_t s);

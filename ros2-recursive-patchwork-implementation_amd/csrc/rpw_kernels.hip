@@ -622,7 +622,7 @@ __device__ __forceinline__ MaskOut w1_mask_loop(const NodeRef& nd, const MaskPrm
 
 __device__ __attribute__((noinline)) MaskOut w1_mask_pass(NodeRef nd_in, int mode, MaskPrm prm)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const NodeRef nd = uni(nd_in);
     prm.cx = uni(prm.cx); prm.cy = uni(prm.cy); prm.cz = uni(prm.cz); prm.nx = uni(prm.nx); prm.ny = uni(prm.ny); prm.nz = uni(prm.nz);
     prm.thr = uni(prm.thr);
@@ -639,9 +639,11 @@ __device__ __attribute__((noinline)) MaskOut w1_mask_pass(NodeRef nd_in, int mod
 // groups of four addends that the chunks before it left in the ring are added; their first reads are issued before the
 // chunk's arithmetic and return under it.
 // fused ring: kFSlots slots of 64 addends x 3 rows (row stride kLdw, like a sweep slot); addend p lives in slot (p / 64) % kFSlots,
-// column p % 64. Columns 64..67 of slot 0 take the stores of the lanes that hold no inlier.
+// column p % 64. The lanes that hold no inlier store into a dump row of their own behind the slots (one entry per lane:
+// seven lanes per entry of a four-entry dump made every store a seven-way bank conflict).
 constexpr int kFSlots = 8;
 constexpr int kFSlotFloats = 3 * kLdw;
+constexpr int kFDump = kFSlots * kFSlotFloats;
 __device__ __forceinline__ uint32_t fused_ring_pos(uint32_t p) { return ((p >> 6) & (uint32_t)(kFSlots - 1)) * (uint32_t)kFSlotFloats + (p & 63u); }
 struct FusedOut { uint32_t count, changed, differs_prev; float sx, sy, sz; };
 
@@ -655,6 +657,8 @@ struct FusedChain {
     uint32_t cs = 0;                   // slots added so far
     bool have_a = false;               // A holds the first half of slot cs
     v4f A[8], B[8];
+    __device__ __forceinline__ void reserve(uint32_t) {}           // (the server form waits for ring space here)
+    __device__ __forceinline__ float result(int k) const { return __shfl(acc, k); }
     // add the slots [cs, avail): all of them are complete in the ring
     __device__ __forceinline__ void consume(const lds_f32* rowp, uint32_t avail)
     {
@@ -693,10 +697,10 @@ struct FusedChain {
         }
     }
 };
-static_assert(kFSlots * kFSlotFloats <= 2 * kGatherTiles, "the fused ring must fit the union");
+static_assert(kFDump + 2 * kLdw + kWave <= 2 * kGatherTiles, "the fused ring and its dump rows must fit the union");
 
-template <int MODE, int IW>
-__device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskPrm& prm, lds_f32* ring, int lane)
+template <int MODE, int IW, class CH>
+__device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskPrm& prm, lds_f32* ring, int lane, CH& ch)
 {
     typedef __attribute__((address_space(1))) char g_char;
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -706,7 +710,6 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
     const uint32_t nfull = n / kWave;
     uint32_t cursor = 0;                                           // inliers so far = addends written
     bool changed = false, differs_prev = false;
-    FusedChain ch;
     const int row = lane < 3 ? lane : 2;
     const lds_f32* rowp = ring + row * kLdw;
     auto step = [&](const P4& r, uint32_t c, auto full) __attribute__((always_inline)) {
@@ -737,7 +740,7 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
         if (FULL) il_store<IW>(il, ip, i);
         else if (ok) il_store<IW>(il, ip, i);
         // centroid addends: an inlier to its place in the ring, everybody else into the dump entries
-        const uint32_t lp = (fused_ring_pos(p) & sel) | ((64u + ((uint32_t)lane & 3u)) & ~sel);
+        const uint32_t lp = (fused_ring_pos(p) & sel) | (((uint32_t)kFDump + (uint32_t)lane) & ~sel);
         lds_f32* w = ring + lp;
         w[0] = r.x; w[kLdw] = r.y; w[2 * kLdw] = r.z;
         cursor += (uint32_t)__popcll(m);
@@ -754,6 +757,7 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
         auto round = [&]() __attribute__((always_inline)) {
             // (the reloads clamp to the last full chunk: loads past it would be wasted, never wrong)
             const uint32_t b4 = (c + 4) * kWave, b5 = b4 + kWave, b6 = b5 + kWave, b7 = b6 + kWave;
+            ch.reserve(cursor + 4u * kWave);
             __builtin_amdgcn_sched_barrier(0);
             step(r0, c, yes());     r0 = w1_load(nd, (b4 < lastfull ? b4 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
             step(r1, c + 1, yes()); r1 = w1_load(nd, (b5 < lastfull ? b5 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
@@ -767,34 +771,36 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
     }
     for (; c < nfull; ++c) {                                       // up to three full chunks left
         const P4 r = w1_load(nd, c * kWave + lane);
+        ch.reserve(cursor + kWave);
         step(r, c, yes()); ch.consume(rowp, cursor >> 6);
     }
     if (nfull * kWave < n) {                                       // the partial chunk
         const uint32_t i = nfull * kWave + lane;
         const P4 r = w1_load(nd, i < n ? i : n - 1u);
+        ch.reserve(cursor + kWave);
         step(r, nfull, no()); ch.consume(rowp, cursor >> 6);
     }
     ch.finish(ring, rowp, cursor, lane);
-    const float acc = ch.acc;
     FusedOut o;
     o.count = cursor;
     o.changed = ballot64(changed) != 0ull ? 1u : 0u;
     o.differs_prev = ballot64(differs_prev) != 0ull ? 1u : 0u;
-    o.sx = __shfl(acc, 0); o.sy = __shfl(acc, 1); o.sz = __shfl(acc, 2);
+    o.sx = ch.result(0); o.sy = ch.result(1); o.sz = ch.result(2);
     return o;
 }
 
 __device__ __attribute__((noinline)) FusedOut w1_fused_pass(NodeRef nd_in, int mode, MaskPrm prm, lds_f32* ring)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const NodeRef nd = uni(nd_in);
     prm.cx = uni(prm.cx); prm.cy = uni(prm.cy); prm.cz = uni(prm.cz); prm.nx = uni(prm.nx); prm.ny = uni(prm.ny); prm.nz = uni(prm.nz);
     prm.thr = uni(prm.thr);
     ring = (lds_f32*)(uintptr_t)uni((uint32_t)(uintptr_t)ring);
     const bool narrow = nd.n <= 65536u;
+    FusedChain ch;
     if (uni((uint32_t)mode) == (uint32_t)kMaskPlane)
-        return narrow ? w1_fused_loop<kMaskPlane, 2>(nd, prm, ring, lane) : w1_fused_loop<kMaskPlane, 4>(nd, prm, ring, lane);
-    return narrow ? w1_fused_loop<kMaskSeed, 2>(nd, prm, ring, lane) : w1_fused_loop<kMaskSeed, 4>(nd, prm, ring, lane);
+        return narrow ? w1_fused_loop<kMaskPlane, 2>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskPlane, 4>(nd, prm, ring, lane, ch);
+    return narrow ? w1_fused_loop<kMaskSeed, 2>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskSeed, 4>(nd, prm, ring, lane, ch);
 }
 
 struct X3 { float x, y, z; };
@@ -941,7 +947,7 @@ __device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count
 
 __device__ __attribute__((noinline)) Sums6 w1_chain_sweep(NodeRef nd_in, uint32_t count, int mode, int indexed, SweepPrm prm, lds_f32* ring)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const NodeRef nd = uni(nd_in);
     count = uni(count);
     prm.a = uni(prm.a); prm.b = uni(prm.b); prm.c = uni(prm.c); prm.d = uni(prm.d); prm.e = uni(prm.e); prm.f = uni(prm.f);
@@ -1112,7 +1118,7 @@ __device__ __forceinline__ void w2_fused_feed(const NodeRef& nd, const MaskPrm& 
         const uint32_t ip = (p & sel) | ((n - 1u) & ~sel);
         if (FULL) il_store<IW>(il, ip, i);
         else if (ok) il_store<IW>(il, ip, i);
-        const uint32_t lp = (fused_ring_pos(p) & sel) | ((64u + ((uint32_t)lane & 3u)) & ~sel);
+        const uint32_t lp = (fused_ring_pos(p) & sel) | (((uint32_t)kFDump + (uint32_t)lane) & ~sel);
         lds_f32* w = ring + lp;
         w[0] = r.x; w[kLdw] = r.y; w[2 * kLdw] = r.z;
         cursor += (uint32_t)__popcll(m);
@@ -1362,7 +1368,7 @@ struct GatherArgs {
 };
 __device__ __attribute__((noinline)) Box6 w1_gather(GatherArgs g, lds_word* toff, lds_word* tsrc)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint32_t nt = g.nt;
     const bool in_lds = nt <= (uint32_t)kGatherTiles;
     if (in_lds) {
@@ -1428,35 +1434,328 @@ __device__ __attribute__((noinline)) Box6 w1_gather(GatherArgs g, lds_word* toff
     return b;
 }
 
+// ==========================================================================================
+// CHAIN-SERVER FORM (the default). In the forms above every dependent add is a whole vector instruction that keeps 3 or 6
+// of 64 lanes busy, and a saturated SIMD issues one vector instruction per ~4.6 cycles whatever its lane mask
+// (tools/microbench_exec.hip): with one chain per wave the chip spends most of its issue slots on those adds. Here a
+// workgroup is one SERVER wave + kSrvFeeders FEEDER waves:
+//   feeder f : owns one patch at a time (taken from the launch's work counter, largest size bucket first) and runs
+//              everything of the forms above EXCEPT the dependent adds: it writes each slot of 64 addends into its ring,
+//              publishes the slot count, and at the end of a pass collects the sums;
+//   server   : lanes 6f .. 6f+5 hold the up-to-six accumulators of feeder f. One round = one slot of 64 addends for EVERY
+//              feeder that has one ready -- the same 64 add instructions serve all of them. A lane with nothing to add
+//              reads a slot of -0.0f (x + -0.0f == x exactly), so the round is branch-free.
+// A feeder's sums are still ((a0 + a1) + a2) + ... in element order from +0: each ring is added by one lane per row, slot
+// after slot. Hand-over is by LDS words only (no s_barrier: the eight waves run independent control flow):
+//   feed[f] = {slots published (counts up for ever), that counter's value when the pass began, layout, rows}   feeder -> server
+//   cons[f] = slots added, acc[f][row] = the accumulator after them                                      server -> feeder
+// One wave's LDS operations are performed in order, so "addends, then the count" / "accumulator, then cons" need no fence.
+// Waits are polls with s_sleep and a spin limit (a protocol error ends the launch with an error flag, not a hung GPU).
+// ==========================================================================================
+constexpr int kSrvFeeders = 7;
+constexpr int kSrvSweepSlots = 4;        // ring slots of a sweep (6 rows of 64 each); the fused pass uses kFSlots slots of 3 rows
+constexpr uint32_t kSrvSpinLimit = 1u << 22;
+static_assert(kSrvSweepSlots * kSlotFloats <= 2 * kGatherTiles, "the server form's sweep ring must fit the union");
+static_assert(6 * kSrvFeeders <= kWave, "six server lanes per feeder");
+
+struct SrvShared {
+    __attribute__((aligned(16))) uint32_t feed[8][4];
+    __attribute__((aligned(16))) float acc[8][8];
+    __attribute__((aligned(16))) float zero[64];
+    uint32_t cons[8];
+    uint32_t done;                     // feeders that have left
+    uint32_t error;                    // a wait ran into the spin limit
+    uint32_t pad[2];
+};
+__device__ __forceinline__ uint32_t srv_layout(uint32_t stride, uint32_t slots) { return stride | ((slots - 1u) << 16); }
+
+// what a feeder needs of the hand-over block (LDS pointers, wave-uniform)
+struct SrvPort {
+    lds_word* fw;                      // feed[f]
+    lds_word* cw;                      // &cons[f]
+    lds_f32* accp;                     // acc[f]
+    lds_word* err;                     // &error
+};
+__device__ __forceinline__ SrvPort srv_port(SrvShared* sv, int f)
+{
+    SrvPort pt;
+    pt.fw = (lds_word*)sv->feed[f]; pt.cw = (lds_word*)&sv->cons[f]; pt.accp = (lds_f32*)sv->acc[f]; pt.err = (lds_word*)&sv->error;
+    return pt;
+}
+__device__ __forceinline__ uint32_t srv_begin(const SrvPort& pt, uint32_t layout, uint32_t rows, int lane)
+{
+    const uint32_t start = uni(*(volatile lds_word*)pt.fw);
+    if (lane == 0) { pt.fw[1] = start; pt.fw[2] = layout; pt.fw[3] = rows; }
+    return start;
+}
+__device__ __forceinline__ void srv_publish(const SrvPort& pt, uint32_t abs_slots, int lane)
+{
+    if (lane == 0) *(volatile lds_word*)pt.fw = abs_slots;
+}
+// until the server has added `need` slots (absolute count); `seen` caches the last value read
+__device__ __forceinline__ void srv_wait(const SrvPort& pt, uint32_t need, uint32_t& seen)
+{
+    uint32_t spins = 0;
+    while ((int32_t)(seen - need) < 0) {
+        seen = uni(*(volatile lds_word*)pt.cw);
+        const uint32_t broken = uni(*(volatile lds_word*)pt.err);
+        if ((int32_t)(seen - need) >= 0 || broken) break;          // (after one time-out nobody in the workgroup waits again)
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSrvSpinLimit) { *(volatile lds_word*)pt.err = 1u; break; }
+    }
+}
+
+// The server wave. Round k adds slot `cons` of every ready ring; the hand-over words for round k + 1 are read at the start
+// of round k and turned into addresses in the middle of it, so that the first half of the next slots is requested under
+// the second half of this round's adds: the 64 dependent adds of consecutive rounds follow each other without a gap.
+// The wave runs at raised priority: its adds are the critical path of up to seven patches, and an add issues only every
+// ~8 cycles -- the feeders' instructions fit in between.
+__device__ __attribute__((noinline)) void srv_loop(SrvShared* sv, Fit1Shared* shs)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4f lds_f4;
+    typedef __attribute__((address_space(3))) v4u lds_u4;
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / 6, row = lane - 6 * grp;
+    const bool valid = grp < kSrvFeeders;
+    const int g = valid ? grp : 0;
+    const lds_f32* ringrow = (lds_f32*)shs[g].ring + row * kLdw;
+    const lds_f32* zero = (lds_f32*)sv->zero;
+    volatile lds_u4* fw = (volatile lds_u4*)sv->feed[g];
+    volatile lds_word* donep = (volatile lds_word*)&sv->done;
+    lds_f32* accw = (lds_f32*)&sv->acc[g][row];
+    lds_word* consw = (lds_word*)&sv->cons[g];
+    uint32_t cons = 0;
+    float acc = 0.0f;
+    v4f A[8], B[8];
+    // what a round needs to know about its slot: is there one (ready), does this lane take part (act), does a pass begin
+    bool ready = false, act = false, first = false;
+    const lds_f32* src = zero;
+    auto look = [&](const v4u& st, uint32_t c) __attribute__((always_inline)) {      // the slot of the round that starts with `c` slots added
+        ready = valid && (int32_t)(st.x - c) > 0;
+        // (all four words are used: a dead fourth word became the compiler's scratch register, and writing it meant
+        // waiting for the read at once)
+        const uint32_t stride = st.z & 0xffffu, nsm = st.z >> 16, rows = st.w;
+        act = ready && (uint32_t)row < rows;
+        first = act && c == st.y;
+        src = act ? ringrow + ((c - st.y) & nsm) * stride : zero;
+    };
+    for (;;) {
+        // ---- nothing in flight: wait for a slot (or for the feeders to leave) ----
+        uint32_t idle = 0;
+        for (;;) {
+            const v4u st = *fw;
+            const uint32_t done = *donep;
+            look(st, cons);
+            if (ballot64(ready) != 0ull) break;
+            if (uni(done) >= (uint32_t)kSrvFeeders || ++idle > kSrvSpinLimit) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const lds_f4*>(src + 4 * q);
+        // ---- rounds back to back while there is work ----
+        for (;;) {
+            acc = first ? 0.0f : acc;                              // the first slot of a pass: Zero(), then +=
+            const bool ready_k = ready, act_k = act;
+            const lds_f32* src_k = src;
+            const v4u nst = *fw;                                   // hand-over words for the next round, requested now
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { B[q] = *reinterpret_cast<const lds_f4*>(src_k + 32 + 4 * q); RPW_CHAIN4(acc, A[q]) __builtin_amdgcn_sched_barrier(0); }
+            cons += ready_k ? 1u : 0u;
+            look(nst, cons);
+            const bool more = ballot64(ready) != 0ull;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { A[q] = *reinterpret_cast<const lds_f4*>(src + 4 * q); RPW_CHAIN4(acc, B[q]) __builtin_amdgcn_sched_barrier(0); }
+            if (act_k) *accw = acc;
+            if (ready_k && row == 0) *(volatile lds_word*)consw = cons;
+            if (!more) break;
+        }
+    }
+}
+
+// feeder half of a chain sweep (the server form's w2_sweep_feed): slot s goes to ring slot s % kSrvSweepSlots once the
+// server has added slot s - kSrvSweepSlots
+template <int MODE, int IW>
+__device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t count, const SweepPrm& prm, lds_f32* ring, const SrvPort& pt, int lane)
+{
+    constexpr int K = SweepRows<MODE>::K;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) const char g_cchar;
+    g_cchar* il = reinterpret_cast<g_cchar*>(nd.il);
+    const uint32_t nslots = (count + kWave - 1) / kWave;
+    const uint32_t last = count - 1u;
+    auto index_of = [&](uint32_t u) -> uint32_t {
+        const uint32_t j = u * kWave + lane, jc = j < last ? j : last;
+        return IW ? il_load<(IW ? IW : 4)>(il, jc) : jc;
+    };
+    auto point_of = [&](uint32_t idx) -> X3 {
+        X3 q; q.x = ldg_f32(nd.x, idx); q.y = ldg_f32(nd.y, idx);
+        q.z = (MODE == kSweepXYZ || MODE == kSweepCov || MODE == kSweepDist) ? ldg_f32(nd.z, idx) : 0.0f;
+        return q;
+    };
+    const uint32_t start = srv_begin(pt, srv_layout((uint32_t)kSlotFloats, (uint32_t)kSrvSweepSlots), (uint32_t)K, lane);
+    uint32_t seen = start;
+    // indices two slots ahead of the point loads, points three slots ahead of their addends
+    uint32_t i3 = index_of(3), i4 = index_of(4);
+    X3 p0 = point_of(index_of(0)), p1 = point_of(index_of(1)), p2 = point_of(index_of(2));
+    for (uint32_t s = 0; s < nslots; ++s) {
+        float v[6];
+        const X3 q = p0;
+        if (MODE == kSweepCov) {
+            const f2 dxy = f2{q.x, q.y} - f2{prm.a, prm.b};
+            const float dz = q.z - prm.c;
+            const f2 a = dxy * f2{dxy.x, dxy.x};            // dx*dx, dy*dx
+            const f2 b = f2{dxy.y, dz} * f2{dxy.y, dxy.x};  // dy*dy, dz*dx
+            const f2 c = f2{dz, dz} * f2{dxy.y, dz};        // dz*dy, dz*dz
+            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+        } else if (MODE == kSweepXYZ) { v[0] = q.x; v[1] = q.y; v[2] = q.z; }
+        else if (MODE == kSweepDist)  { v[0] = plane_dist(q.x, q.y, q.z, prm.a, prm.b, prm.c, prm.d, prm.e, prm.f); }
+        else if (MODE == kSweepRange) { v[0] = sqrt_rn(q.x * q.x + q.y * q.y); }
+        else if (MODE == kSweepXY)    { v[0] = q.x; v[1] = q.y; }
+        else { const float dx = q.x - prm.a, dy = q.y - prm.b; v[0] = dx * dx; v[1] = dy * dy; }
+        if (s >= (uint32_t)kSrvSweepSlots) srv_wait(pt, start + s - (uint32_t)(kSrvSweepSlots - 1), seen);
+        lds_f32* dst = ring + (s % (uint32_t)kSrvSweepSlots) * kSlotFloats + lane;
+        const bool live = s * kWave + lane < count;           // columns past the end: -0.0f, the exact additive identity
+#pragma unroll
+        for (int k = 0; k < K; ++k) dst[k * kLdw] = live ? v[k] : -0.0f;
+        srv_publish(pt, start + s + 1u, lane);
+        p0 = p1; p1 = p2; p2 = point_of(i3); i3 = i4; i4 = index_of(s + 5);
+    }
+    srv_wait(pt, start + nslots, seen);
+    Sums6 out;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out.v[k] = k < K ? *(volatile lds_f32*)(pt.accp + k) : 0.0f;
+    return out;
+}
+
+__device__ __attribute__((noinline)) Sums6 srv_chain_sweep(NodeRef nd_in, uint32_t count, int mode, SweepPrm prm, lds_f32* ring, SrvShared* sv, int f)
+{
+    const int lane = threadIdx.x & 63;
+    const NodeRef nd = uni(nd_in);
+    count = uni(count);
+    prm.a = uni(prm.a); prm.b = uni(prm.b); prm.c = uni(prm.c); prm.d = uni(prm.d); prm.e = uni(prm.e); prm.f = uni(prm.f);
+    ring = (lds_f32*)(uintptr_t)uni((uint32_t)(uintptr_t)ring);
+    sv = uni_ptr(sv);
+    const SrvPort pt = srv_port(sv, (int)uni((uint32_t)f));
+    Sums6 out;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out.v[k] = 0.0f;
+    if (count == 0) return out;
+    const bool narrow = nd.n <= 65536u;                // the width the pass that wrote the list used
+    switch (__builtin_amdgcn_readfirstlane(mode)) {
+    case kSweepCov:   return narrow ? srv_sweep_loop<kSweepCov, 2>(nd, count, prm, ring, pt, lane) : srv_sweep_loop<kSweepCov, 4>(nd, count, prm, ring, pt, lane);
+    case kSweepXYZ:   return narrow ? srv_sweep_loop<kSweepXYZ, 2>(nd, count, prm, ring, pt, lane) : srv_sweep_loop<kSweepXYZ, 4>(nd, count, prm, ring, pt, lane);
+    case kSweepDist:  return narrow ? srv_sweep_loop<kSweepDist, 2>(nd, count, prm, ring, pt, lane) : srv_sweep_loop<kSweepDist, 4>(nd, count, prm, ring, pt, lane);
+    case kSweepRange: return srv_sweep_loop<kSweepRange, 0>(nd, count, prm, ring, pt, lane);
+    case kSweepXY:    return srv_sweep_loop<kSweepXY, 0>(nd, count, prm, ring, pt, lane);
+    default:          return srv_sweep_loop<kSweepVarXY, 0>(nd, count, prm, ring, pt, lane);
+    }
+}
+
+// the fused pass's chain, handed to the server: "consume" publishes, "finish" pads, publishes and collects
+struct SrvChain {
+    SrvPort pt;
+    uint32_t start, seen;
+    int lane;
+    float sums[3];
+    __device__ __forceinline__ void begin(const SrvPort& port, int ln)
+    {
+        pt = port; lane = ln;
+        start = srv_begin(pt, srv_layout((uint32_t)kFSlotFloats, (uint32_t)kFSlots), 3u, lane);
+        seen = start;
+    }
+    // the coming chunks write addends below position `upto`: their ring slots must have been added
+    __device__ __forceinline__ void reserve(uint32_t upto)
+    {
+        const uint32_t smax = (upto - 1u) >> 6;
+        if (smax >= (uint32_t)kFSlots) srv_wait(pt, start + smax - (uint32_t)(kFSlots - 1), seen);
+    }
+    __device__ __forceinline__ void consume(const lds_f32*, uint32_t avail) { srv_publish(pt, start + avail, lane); }
+    __device__ __forceinline__ void finish(lds_f32* ring, const lds_f32*, uint32_t cursor, int)
+    {
+        sums[0] = sums[1] = sums[2] = 0.0f;
+        if (cursor == 0) return;
+        if ((cursor & 63u) && (uint32_t)lane >= (cursor & 63u)) {
+            lds_f32* w = ring + fused_ring_pos((cursor & ~63u) + (uint32_t)lane);
+            w[0] = -0.0f; w[kLdw] = -0.0f; w[2 * kLdw] = -0.0f;
+        }
+        const uint32_t total = (cursor + 63u) >> 6;
+        srv_publish(pt, start + total, lane);
+        srv_wait(pt, start + total, seen);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sums[k] = *(volatile lds_f32*)(pt.accp + k);
+    }
+    __device__ __forceinline__ float result(int k) const { return sums[k]; }
+};
+
+__device__ __attribute__((noinline)) FusedOut srv_fused_pass(NodeRef nd_in, int mode, MaskPrm prm, lds_f32* ring, SrvShared* sv, int f)
+{
+    const int lane = threadIdx.x & 63;
+    const NodeRef nd = uni(nd_in);
+    prm.cx = uni(prm.cx); prm.cy = uni(prm.cy); prm.cz = uni(prm.cz); prm.nx = uni(prm.nx); prm.ny = uni(prm.ny); prm.nz = uni(prm.nz);
+    prm.thr = uni(prm.thr);
+    ring = (lds_f32*)(uintptr_t)uni((uint32_t)(uintptr_t)ring);
+    sv = uni_ptr(sv);
+    const bool narrow = nd.n <= 65536u;
+    SrvChain ch;
+    ch.begin(srv_port(sv, (int)uni((uint32_t)f)), lane);
+    if (uni((uint32_t)mode) == (uint32_t)kMaskPlane)
+        return narrow ? w1_fused_loop<kMaskPlane, 2>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskPlane, 4>(nd, prm, ring, lane, ch);
+    return narrow ? w1_fused_loop<kMaskSeed, 2>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskSeed, 4>(nd, prm, ring, lane, ch);
+}
+
+// workgroup set-up and the feeder's good-bye
+constexpr size_t kSrvLdsBytes = sizeof(SrvShared) + (size_t)kSrvFeeders * sizeof(Fit1Shared);
+static_assert(sizeof(SrvShared) % 16 == 0, "the feeders' blocks follow the hand-over block, 16-byte aligned");
+__device__ __forceinline__ void srv_init(SrvShared* sv)
+{
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x;
+        if (t < 32) (&sv->feed[0][0])[t] = 0u;
+        (&sv->acc[0][0])[t] = 0.0f;
+        sv->zero[t] = -0.0f;
+        if (t < 8) sv->cons[t] = 0u;
+        if (t == 0) { sv->done = 0u; sv->error = 0u; }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void srv_leave(SrvShared* sv, int lane)
+{
+    wave_sync();
+    if (lane == 0) atomicAdd(&sv->done, 1u);
+}
+
 // W = 1: one wave per patch (16 patches per CU: the throughput form). W = 2: chain wave + helper wave (8 patches per CU:
 // the latency form, about half the time per patch); the host picks by the number of patches in the launch.
-template <int W>
-__global__ __launch_bounds__(kFit1Threads * W, 4) void patch_fit1_kernel(DevParams p)
+// work item -> patch, largest size bucket first; false when the launch has fewer patches than that
+__device__ __forceinline__ bool patch_of_item(const DevParams& p, uint32_t item, int lane, uint32_t& linear)
 {
-    __shared__ Fit1Shared sh;
-    const int lane = threadIdx.x & 63;
-#define W1_PH(IDX, CNT, ...) { __VA_ARGS__; }
-    // the passes that run a chain: single-wave form, or chain half here + feeding half on the helper wave
-#define W_SWEEP(ND, M, MODE, INDEXED, PRM) (W == 2 ? w2_chain_sweep(&sh, ND, M, MODE, PRM) : w1_chain_sweep(ND, M, MODE, INDEXED, PRM, ring))
-#define W_FUSED(ND, MODE, PRM) (W == 2 ? w2_fused_pass(&sh, ND, MODE, PRM) : w1_fused_pass(ND, MODE, PRM, ring))
-#define W_LEAVE() { if (W == 2) { if (lane == 0) sh.cmd[0] = (uint32_t)kCmdExit; w2_barrier(); } }
+    const uint32_t cnt = p.bucket_count[kBuckets - 1 - lane];
+    const uint32_t incl = wave_incl_scan(cnt);
+    const uint32_t total = __shfl(incl, 63);
+    if (item >= total) return false;
+    const unsigned long long bm = ballot64(item < incl);
+    const int l = __ffsll((long long)bm) - 1;
+    const uint32_t before = __shfl(incl - cnt, l);
+    linear = p.bucket_list[(size_t)(kBuckets - 1 - l) * p.list_stride + (item - before)];
+    return true;
+}
 
-    // ---- block -> patch, largest size bucket first --------------------------------------------
-    uint32_t linear;
-    {
-        const uint32_t cnt = p.bucket_count[kBuckets - 1 - lane];
-        const uint32_t incl = wave_incl_scan(cnt);
-        const uint32_t total = __shfl(incl, 63);
-        if (blockIdx.x >= total) return;
-        const unsigned long long bm = ballot64(blockIdx.x < incl);
-        const int l = __ffsll((long long)bm) - 1;
-        const uint32_t before = __shfl(incl - cnt, l);
-        linear = p.bucket_list[(size_t)(kBuckets - 1 - l) * p.list_stride + (blockIdx.x - before)];
-    }
-    if (W == 2 && threadIdx.x >= 64) {                 // the helper wave: serves the chain wave until told to leave
-        w2_helper_loop(&sh);
-        return;
-    }
+// One patch, on the wave that owns it. W = 1: alone; W = 2: with the helper wave of its workgroup; W = 3: as feeder `feeder`
+// of a chain-server workgroup.
+template <int W>
+__device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, uint32_t linear, int lane, SrvShared* sv, int feeder)
+{
+#define W1_PH(IDX, CNT, ...) { __VA_ARGS__; }
+    // the passes that run a chain: single-wave form, chain half here + feeding half on the helper wave, or feeding half here
+    // + the adds on the server wave
+#define W_SWEEP(ND, M, MODE, INDEXED, PRM) (W == 3 ? srv_chain_sweep(ND, M, MODE, PRM, ring, sv, feeder) : W == 2 ? w2_chain_sweep(&sh, ND, M, MODE, PRM) : w1_chain_sweep(ND, M, MODE, INDEXED, PRM, ring))
+#define W_FUSED(ND, MODE, PRM) (W == 3 ? srv_fused_pass(ND, MODE, PRM, ring, sv, feeder) : W == 2 ? w2_fused_pass(&sh, ND, MODE, PRM) : w1_fused_pass(ND, MODE, PRM, ring))
+#define W_LEAVE() { if (W == 2) { if (lane == 0) sh.cmd[0] = (uint32_t)kCmdExit; w2_barrier(); } }
     const int frame = (int)(linear / (uint32_t)p.P), patch = (int)(linear % (uint32_t)p.P);
     const PatchDesc pd = p.patches[linear];
     const uint32_t fo = p.frame_off[frame];
@@ -1764,6 +2063,46 @@ __global__ __launch_bounds__(kFit1Threads * W, 4) void patch_fit1_kernel(DevPara
         atomicAdd((unsigned long long*)&st->total_iterations, pa.iters);
     }
 }
+#undef W1_PH
+#undef W_SWEEP
+#undef W_FUSED
+#undef W_LEAVE
+
+template <int W>
+__global__ __launch_bounds__(kFit1Threads * W, 4) void patch_fit1_kernel(DevParams p)
+{
+    __shared__ Fit1Shared sh;
+    const int lane = threadIdx.x & 63;
+    uint32_t linear;
+    if (!patch_of_item(p, blockIdx.x, lane, linear)) return;
+    if (W == 2 && threadIdx.x >= 64) {                 // the helper wave: serves the chain wave until told to leave
+        w2_helper_loop(&sh);
+        return;
+    }
+    fit_patch<W>(p, sh, linear, lane, nullptr, 0);
+}
+
+// The chain-server form: wave 0 adds, waves 1..kSrvFeeders take patches from the launch's work counter until it runs out.
+__global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void patch_fit_srv_kernel(DevParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char srv_lds[];
+    SrvShared* sv = reinterpret_cast<SrvShared*>(srv_lds);
+    Fit1Shared* shs = reinterpret_cast<Fit1Shared*>(srv_lds + sizeof(SrvShared));
+    srv_init(sv);
+    const int lane = threadIdx.x & 63, f = (int)(threadIdx.x >> 6) - 1;
+    if (f < 0) { srv_loop(sv, shs); return; }
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(p.work, 1u);
+        item = uni(item);
+        uint32_t linear;
+        if (!patch_of_item(p, item, lane, linear)) break;
+        fit_patch<3>(p, shs[f], linear, lane, sv, f);
+        wave_sync();
+    }
+    if (lane == 0 && *(volatile uint32_t*)&sv->error) atomicOr(p.work + 1, 1u);      // a wait timed out: the host reports it
+    srv_leave(sv, lane);
+}
 
 // ------------------------------------------------------------------------------------------
 // debug kernels (test hooks)
@@ -1815,6 +2154,39 @@ __global__ __launch_bounds__(kFit1Threads * W, 4) void w1_loop_bench_kernel(cons
     if (lane == 0) out[blockIdx.x] = acc;
 }
 
+// the same loops in the chain-server form: workgroup b's feeder f runs them on node b * kSrvFeeders + f
+__global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void srv_loop_bench_kernel(const float* sx, const float* sy, const float* sz, uint8_t* mask,
+                                                                                     uint32_t* il, uint32_t n, uint32_t count, int what, int reps, uint32_t nodes, float* out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char srv_lds[];
+    SrvShared* sv = reinterpret_cast<SrvShared*>(srv_lds);
+    Fit1Shared* shs = reinterpret_cast<Fit1Shared*>(srv_lds + sizeof(SrvShared));
+    srv_init(sv);
+    const int lane = threadIdx.x & 63, f = (int)(threadIdx.x >> 6) - 1;
+    if (f < 0) { srv_loop(sv, shs); return; }
+    const uint32_t node = blockIdx.x * (uint32_t)kSrvFeeders + (uint32_t)f;
+    if (node < nodes) {
+        lds_f32* ring = (lds_f32*)shs[f].ring;
+        const size_t base = (size_t)node * n;
+        NodeRef nd; nd.x = (g_cf32*)(sx + base); nd.y = (g_cf32*)(sy + base); nd.z = (g_cf32*)(sz + base);
+        nd.m = (g_u8*)(mask + base); nd.il = (g_u32*)(il + base); nd.n = n;
+        float acc = 0.0f;
+        for (int r = 0; r < reps; ++r) {
+            if (what < 16) {
+                SweepPrm prm; prm.a = 0.25f + acc * 0.0f; prm.b = -0.5f; prm.c = 0.125f; prm.d = 0.0f; prm.e = 0.0f; prm.f = 1.0f;
+                const Sums6 v = srv_chain_sweep(nd, count, what, prm, ring, sv, f);
+                acc += v.v[0];
+            } else {
+                MaskPrm mp; mp.cx = 0.0f; mp.cy = 0.0f; mp.cz = acc * 0.0f; mp.nx = 0.0f; mp.ny = 0.0f; mp.nz = 1.0f; mp.thr = 0.6f;
+                if (what == 18) { const MaskOut o = w1_mask_pass(nd, kMaskOlder, mp); acc += (float)o.count; }
+                else { const FusedOut o = srv_fused_pass(nd, what - 16, mp, ring, sv, f); acc += (float)o.count + o.sx * 0.0f; }
+            }
+        }
+        if (lane == 0) out[node] = acc + (float)sv->error * 1.0e30f;
+    }
+    srv_leave(sv, lane);
+}
+
 // ------------------------------------------------------------------------------------------
 // per-frame result record of a batch, as four int32: ground points, non-ground points of the zone, patches, refits
 // (what the multi-GPU result gather exchanges: reference callers get exactly these counts, recursive_patchwork.cpp:421-423)
@@ -1838,7 +2210,8 @@ __global__ __launch_bounds__(256) void frame_setup_kernel(uint32_t* offsets, uin
 // labels (and residuals, and the stats record) of one frame: device memory -> pinned host memory, 16 bytes per lane
 __global__ __launch_bounds__(256) void frame_copy_out_kernel(const uint8_t* __restrict__ labels, uint8_t* __restrict__ h_labels, uint32_t n,
                                                              const float* __restrict__ res, float* __restrict__ h_res,
-                                                             const rpw_frame_stats* __restrict__ stats, rpw_frame_stats* __restrict__ h_stats)
+                                                             const rpw_frame_stats* __restrict__ stats, rpw_frame_stats* __restrict__ h_stats,
+                                                             const uint32_t* __restrict__ fit_error)
 {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     const uint32_t n16 = n / 16u;
@@ -1853,7 +2226,7 @@ __global__ __launch_bounds__(256) void frame_copy_out_kernel(const uint8_t* __re
         for (uint32_t i = tid; i < r4; i += nthreads) rd[i] = rs[i];
         for (uint32_t i = r4 * 4u + tid; i < n; i += nthreads) h_res[i] = res[i];
     }
-    if (tid == 0) *h_stats = *stats;
+    if (tid == 0) { *h_stats = *stats; *reinterpret_cast<uint32_t*>(h_stats + 1) = *fit_error; }      // (the pinned record has a word behind the stats)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1890,12 +2263,18 @@ void launch_fit(const DevParams& p, hipStream_t s)
         const size_t per = (160u * 1024u) / (size_t)k, stat = sizeof(Fit1Shared) + 64;
         return per > stat ? ((per - stat) & ~(size_t)255) : (size_t)0;
     }();
-    // Few patches in the launch (a frame or a few: the host-pointer path) -> the two-wave latency form; a batch that
-    // fills the chip -> the single-wave throughput form. RPW_FIT_WAVES=1|2 forces one (tests, A/B measurements).
+    // RPW_FIT_WAVES=1|2|3 forces a form (tests, A/B measurements): one wave per patch, chain + helper wave, chain server.
     static const int forced = [] { const char* e = getenv("RPW_FIT_WAVES"); return e ? atoi(e) : 0; }();
-    const bool two = forced == 2 || (forced != 1 && grid <= 8u * 256u);
-    if (two) hipLaunchKernelGGL(patch_fit1_kernel<2>, dim3(grid), dim3(2 * kFit1Threads), pad, s, p);
-    else     hipLaunchKernelGGL(patch_fit1_kernel<1>, dim3(grid), dim3(kFit1Threads), pad, s, p);
+    if (forced == 1) { hipLaunchKernelGGL(patch_fit1_kernel<1>, dim3(grid), dim3(kFit1Threads), pad, s, p); return; }
+    // few patches in the launch (a frame or a few: the host-pointer path) -> a chain wave + a helper wave per patch, the form
+    // with the shortest time per patch; a batch -> the chain-server form, the one with the fewest instructions per point
+    if (forced == 2 || (forced == 0 && grid <= 8u * 256u)) { hipLaunchKernelGGL(patch_fit1_kernel<2>, dim3(grid), dim3(2 * kFit1Threads), pad, s, p); return; }
+    // chain-server form: persistent workgroups (two fit a CU), each feeder pulls patches until the work counter runs out
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(patch_fit_srv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSrvLdsBytes);
+    (void)once;
+    uint32_t wgs = (grid + (uint32_t)kSrvFeeders - 1u) / (uint32_t)kSrvFeeders;
+    if (wgs > 2u * 256u) wgs = 2u * 256u;
+    hipLaunchKernelGGL(patch_fit_srv_kernel, dim3(wgs), dim3(kWave * (1 + kSrvFeeders)), kSrvLdsBytes, s, p);
 }
 void launch_result_record(const rpw_frame_stats* stats, int32_t* out, uint32_t n_frames, hipStream_t s)
 {
@@ -1906,18 +2285,25 @@ void launch_frame_setup(uint32_t* offsets, uint32_t n, uint32_t tiles, uint32_t*
     hipLaunchKernelGGL(frame_setup_kernel, dim3(1), dim3(256), 0, s, offsets, n, tiles, ctrl, ctrl_words);
 }
 void launch_frame_copy_out(const uint8_t* labels, uint8_t* h_labels, uint32_t n, const float* res, float* h_res,
-                           const rpw_frame_stats* stats, rpw_frame_stats* h_stats, hipStream_t s)
+                           const rpw_frame_stats* stats, rpw_frame_stats* h_stats, const uint32_t* fit_error, hipStream_t s)
 {
     uint32_t blocks = (n / 16u + 255u) / 256u;
     if (blocks < 1) blocks = 1;
     if (blocks > 64) blocks = 64;
-    hipLaunchKernelGGL(frame_copy_out_kernel, dim3(blocks), dim3(256), 0, s, labels, h_labels, n, res, h_res, stats, h_stats);
+    hipLaunchKernelGGL(frame_copy_out_kernel, dim3(blocks), dim3(256), 0, s, labels, h_labels, n, res, h_res, stats, h_stats, fit_error);
 }
 void launch_loop_bench(const float* sx, const float* sy, const float* sz, uint8_t* mask, uint32_t* il, uint32_t n, uint32_t count,
                        int what, int reps, uint32_t blocks, float* out, hipStream_t s)
 {
-    const int w = what >= 32 ? 2 : 1;                 // what + 32: the same loop in the two-wave form
+    const int w = what >= 64 ? 3 : (what >= 32 ? 2 : 1);      // what + 32: the same loop in the two-wave form, + 64: chain-server form
     what &= 31;
+    if (w == 3) {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(srv_loop_bench_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSrvLdsBytes);
+        (void)once;
+        const uint32_t wgs = (blocks + (uint32_t)kSrvFeeders - 1u) / (uint32_t)kSrvFeeders;
+        hipLaunchKernelGGL(srv_loop_bench_kernel, dim3(wgs), dim3(kWave * (1 + kSrvFeeders)), kSrvLdsBytes, s, sx, sy, sz, mask, il, n, count, what, reps, blocks, out);
+        return;
+    }
     if (w == 2) hipLaunchKernelGGL(w1_loop_bench_kernel<2>, dim3(blocks), dim3(2 * kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out);
     else        hipLaunchKernelGGL(w1_loop_bench_kernel<1>, dim3(blocks), dim3(kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out);
 }

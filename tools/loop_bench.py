@@ -8,11 +8,12 @@ eng = rpw_amd.Engine(rpw_amd.PatchworkConfig(), max_points=1024, max_frames=1)
 names = {0: "sweep xyz (3 rows)", 1: "sweep cov (6 rows)", 2: "sweep |d| (1 row)", 3: "sweep range (1 row, all slots)",
          17: "fused pass plane (mask + centroid chain)", 16: "fused pass seed (mask + centroid chain)"}
 pct = 56
-for blocks, waves in ((1, 1), (1, 2), (256 * 4, 1), (256 * 4, 2), (256 * 16, 1), (256 * 8, 2)):
-    print(f"--- {blocks} workgroups ({blocks / 256:.0f} per CU) of {waves} wave(s), node of {n} slots, {pct} % inliers")
+FORM = {1: "one wave per node", 2: "chain wave + helper wave per node", 3: "chain-server form (7 nodes per workgroup of 8 waves)"}
+for blocks, waves in ((1, 1), (1, 2), (1, 3), (7, 3), (256 * 4, 1), (256 * 4, 2), (256 * 7, 3), (256 * 16, 1), (256 * 8, 2), (256 * 14, 3), (256 * 28, 3)):
+    print(f"--- {blocks} nodes ({blocks / 256:.1f} per CU), {FORM[waves]}, node of {n} slots, {pct} % inliers")
     for what, nm in names.items():
         reps = 20
-        ms = eng.loop_bench(what + (32 if waves == 2 else 0), n, pct, reps, blocks)
+        ms = eng.loop_bench(what + 32 * (waves - 1), n, pct, reps, blocks)
         elems = n if what in (3, 16, 17) else n * pct // 100
         ns = ms * 1e6 / (reps * elems)
         print(f"  {nm:32s} {ms:9.3f} ms  {ns:7.3f} ns/element/wave = {ns * 2.4:6.2f} cycles;  chip rate {blocks * reps * elems / ms / 1e6:9.1f} G elements/s")
