@@ -917,7 +917,7 @@ rpw_status rpw_debug_loop_bench(rpw_handle* h, int what, uint32_t n, uint32_t in
     if (!h || !ms || n == 0 || blocks == 0 || reps <= 0 || inlier_pct > 100) return RPW_ERR_INVALID;
     if ((uint64_t)n * blocks > (1ull << 28)) return fail(h, RPW_ERR_CAPACITY, "loop bench: n * blocks too large");
     const int base_what = what & 31;
-    if ((what & ~127) || (what & 96) == 96 || !((base_what >= 0 && base_what <= 5) || (base_what >= 16 && base_what <= 18)))
+    if ((what & ~127) || (what & 96) == 96 || !((base_what >= 0 && base_what <= 6) || (base_what >= 16 && base_what <= 18)))
         return fail(h, RPW_ERR_INVALID, "loop bench: unknown loop %d", what);
     RPW_HIP(h, hipSetDevice(h->device));
     const size_t total = (size_t)n * blocks;

@@ -1454,7 +1454,7 @@ __device__ __attribute__((noinline)) Box6 w1_gather(GatherArgs g, lds_word* toff
 // ==========================================================================================
 constexpr int kSrvFeeders = 7;
 constexpr int kSrvSweepSlots = 4;        // ring slots of a sweep (6 rows of 64 each); the fused pass uses kFSlots slots of 3 rows
-constexpr uint32_t kSrvSpinLimit = 1u << 22;
+constexpr uint32_t kSrvSpinLimit = 1u << 25;      // polls (>= ~200 cycles each: seconds) before a wait gives up
 static_assert(kSrvSweepSlots * kSlotFloats <= 2 * kGatherTiles, "the server form's sweep ring must fit the union");
 static_assert(6 * kSrvFeeders <= kWave, "six server lanes per feeder");
 
@@ -2140,7 +2140,13 @@ __global__ __launch_bounds__(kFit1Threads * W, 4) void w1_loop_bench_kernel(cons
     nd.m = (g_u8*)(mask + base); nd.il = (g_u32*)(il + base); nd.n = n;
     float acc = 0.0f;
     for (int r = 0; r < reps; ++r) {
-        if (what < 16) {
+        if (what == 6) {                                           // `count` eigenvector solves (one per refit in patch_fit), covariances of a noisy plane
+            for (uint32_t i = 0; i < count; ++i) {
+                const float t = (float)(i & 15u) * 0.003f + acc * 0.0f;
+                const N3 nr = w1_normal(8.1f + t, 0.31f - t, 7.7f, 0.012f + 0.1f * t, -0.02f, 0.0004f + 0.01f * t);
+                acc += nr.x;
+            }
+        } else if (what < 16) {
             SweepPrm prm; prm.a = 0.25f + acc * 0.0f; prm.b = -0.5f; prm.c = 0.125f; prm.d = 0.0f; prm.e = 0.0f; prm.f = 1.0f;
             const Sums6 v = W == 2 ? w2_chain_sweep(&sh, nd, count, what, prm) : w1_chain_sweep(nd, count, what, 1, prm, ring);
             acc += v.v[0];

@@ -2,6 +2,7 @@
 // (reference test/test_recursive_patchwork.cpp:51-98,146-164), against
 // recursive_patchwork::RecursivePatchwork backed by the HIP library. Seeded instead of random_device.
 #include "recursive_patchwork.hpp"
+#include "ordered_pipeline.hpp"
 #include "rpw_oracle.h"      // the CPU oracle: the checker (tests only)
 
 #include <cassert>
@@ -168,6 +169,32 @@ int main()
         try { (void)pw.waitFrame(0); } catch (const std::exception&) { threw = true; }
         assert(threw);                                                         // nothing in flight
         std::printf("pipeline: %zu frames equal to the synchronous call\n", checked);
+    }
+
+    // ordered pipeline: results come back in submission order and equal the synchronous call, frame by frame,
+    // although the slots finish in any order (frames of very different cost)
+    {
+        PatchworkConfig cfg; cfg.num_sectors = 10;
+        RecursivePatchwork pw(cfg), ref(cfg);
+        OrderedPipeline pipe(pw, 4, 130000);
+        std::vector<std::vector<Point3D>> fr;
+        const int sizes[] = {120000, 500, 60000, 3, 0, 90000, 2049, 130000, 700, 45000, 10, 100000};
+        for (int k = 0; k < 36; ++k) fr.push_back(synthetic(sizes[k % 12], 100 + k));
+        size_t got_n = 0;
+        auto check = [&](std::vector<OrderedPipeline::Result>&& rs) {
+            for (auto& got : rs) {
+                auto want = ref.filterGroundPoints(fr[got_n]);
+                assert(got.first.size() == want.first.size() && got.second.size() == want.second.size());
+                for (size_t i = 0; i < want.first.size(); ++i) assert(std::memcmp(&got.first[i], &want.first[i], 12) == 0);
+                for (size_t i = 0; i < want.second.size(); ++i) assert(std::memcmp(&got.second[i], &want.second[i], 12) == 0);
+                ++got_n;
+            }
+        };
+        for (auto& f : fr) { check(pipe.push(f)); assert(pipe.framesOnGpu() <= 4); }
+        check(pipe.flush());
+        assert(got_n == fr.size() && pipe.framesOnGpu() == 0 && pipe.finishedFramesHeld() == 0);
+        std::printf("ordered pipeline: %zu frames in order, equal to the synchronous call (at most %zu finished frames held)\n",
+                    got_n, pipe.maxFinishedFramesHeld());
     }
 
     // empty input: both empty

@@ -30,8 +30,8 @@ done
 ( cd /tmp && export TMPDIR=/tmp MAX_ITER=1 && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_c5" -o t -- python3 "$ROOT/tools/binning_probe.py" > "$ROOT/$OUT/export/${R}_binning_probe_c5x32.json" 2> "$ROOT/$OUT/stats_c5.err" )
 cp "$(find "$OUT/stats_bench" -name '*kernel_stats.csv' | head -1)" "$OUT/export/${R}_bench_kernel_stats.csv"
 cp "$(find "$OUT/stats_c5" -name '*kernel_stats.csv' | head -1)" "$OUT/export/${R}_binning_probe_c5x32_kernel_stats.csv"
-# launches of a kernel before the timed region: 1 set-up per engine (4) + warm-up (6); timed: 192
-python3 tools/trace_phase_avg.py "$(find "$OUT/stats_bench" -name '*kernel_trace.csv' | head -1)" 10 192 > "$OUT/export/${R}_bench_kernel_trace_summary.json"
+# launches of a kernel before the timed region: 1 set-up per engine (4) + warm-up (6); timed: 224
+python3 tools/trace_phase_avg.py "$(find "$OUT/stats_bench" -name '*kernel_trace.csv' | head -1)" 10 224 > "$OUT/export/${R}_bench_kernel_trace_summary.json"
 # 5. the loop micro-benchmark and the host path probe
 python3 tools/loop_bench.py 8192 > "$OUT/export/${R}_loop_bench.txt" 2>/dev/null
 python3 tools/host_path_probe.py --slots 1,2,4,8,16 > "$OUT/export/${R}_host_path_probe.json" 2>/dev/null
