@@ -543,6 +543,9 @@ def main():
                 out["memory_system"] = {"traffic_bytes_per_step": int(sum(t_all)), "traffic_source": traffic_src,
                                         "ms_per_step": round(step_s * 1e3, 4), "achieved": round(rate, 1), "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": round(rate / HBM_PEAK_GBS, 4),
+                                        # what this chip streams from HBM at full occupancy (tools/microbench_loads.hip,
+                                        # profiles/r02_microbench_loads.txt: 6.24-6.29 TB/s)
+                                        "frac_of_measured_streaming_rate": round(rate / 6260.0, 4),
                                         "note": "FETCH_SIZE x2 + WRITE_SIZE of bin_tile + scan_offsets + patch_fit per launch "
                                                 "(requests that leave L2; Infinity Cache hits are included) / time per step"}
             # the bound that governs patch_fit: sequential binary32 adds. A dependent v_add_f32 retires every
