@@ -9,8 +9,10 @@
 //   K3 patch_fit       scan of the patch's run lengths + gather of its runs (recursive_patchwork.cpp:372-378:
 //                      patch_points in zone order), then fitPlaneAndSplit / fitPlanePCA / computeCentroid / computeCovariance /
 //                      Eigen solve / computePlaneDistances / mask compare / split + recursion
-//                      (recursive_patchwork.cpp:77-308), ONE WAVE per (frame, patch): fused mask + centroid passes and
-//                      self-fed chain sweeps (see the comment in front of patch_fit1_kernel)
+//                      (recursive_patchwork.cpp:77-308). One OWNER wave per (frame, patch) runs the passes; the dependent
+//                      adds of its sequential sums run on the owner itself (patch_fit1_kernel<1>), on the owner while a
+//                      helper wave feeds it (patch_fit1_kernel<2>, launches of few patches), or on a server wave that
+//                      adds for seven owners at once (patch_fit_srv_kernel, batches) -- see launch_fit and DESIGN.md section 4
 //
 // Exactness: every sum the reference accumulates sequentially in binary32 (centroid,
 // covariance, residual, mean distance, variance) is accumulated here in the same order
