@@ -1488,11 +1488,17 @@ __device__ __forceinline__ uint32_t srv_begin(const SrvPort& pt, uint32_t layout
 {
     const uint32_t start = uni(*(volatile lds_word*)pt.fw);
     if (lane == 0) { pt.fw[1] = start; pt.fw[2] = layout; pt.fw[3] = rows; }
+    asm volatile("" ::: "memory");
     return start;
 }
+// (compiler barriers: a volatile access orders only against other volatile accesses, so without them the compiler
+// could sink a slot's plain LDS stores below the count that announces them, or lift stores into a ring slot above the wait for
+// it; the hardware performs one wave's LDS operations in order, so no instruction is needed)
 __device__ __forceinline__ void srv_publish(const SrvPort& pt, uint32_t abs_slots, int lane)
 {
+    asm volatile("" ::: "memory");
     if (lane == 0) *(volatile lds_word*)pt.fw = abs_slots;
+    asm volatile("" ::: "memory");
 }
 // until the server has added `need` slots (absolute count); `seen` caches the last value read
 __device__ __forceinline__ void srv_wait(const SrvPort& pt, uint32_t need, uint32_t& seen)
@@ -1505,6 +1511,7 @@ __device__ __forceinline__ void srv_wait(const SrvPort& pt, uint32_t need, uint3
         __builtin_amdgcn_s_sleep(1);
         if (++spins > kSrvSpinLimit) { *(volatile lds_word*)pt.err = 1u; break; }
     }
+    asm volatile("" ::: "memory");
 }
 
 // The server wave. Round k adds slot `cons` of every ready ring; the hand-over words for round k + 1 are read at the start
@@ -1572,7 +1579,8 @@ __device__ __attribute__((noinline)) void srv_loop(SrvShared* sv, Fit1Shared* sh
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 8; ++q) { A[q] = *reinterpret_cast<const lds_f4*>(src + 4 * q); RPW_CHAIN4(acc, B[q]) __builtin_amdgcn_sched_barrier(0); }
-            if (act_k) *accw = acc;
+            asm volatile("" ::: "memory");                         // the slot's reads are done before its release is announced
+            if (act_k) *(volatile lds_f32*)accw = acc;
             if (ready_k && row == 0) *(volatile lds_word*)consw = cons;
             if (!more) break;
         }
