@@ -20,6 +20,9 @@
 // Built with -ffp-contract=off; divide and sqrt are correctly rounded.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <mutex>
+#include <set>
+#include <utility>
 #include "rpw_internal.h"
 
 namespace rpw {
@@ -2267,6 +2270,19 @@ void launch_scan(const DevParams& p, hipStream_t s)
     int parts = kScanThreads / (p.P + 4); if (parts > 16) parts = 16; if (parts < 1) parts = 1;      // as in the kernel
     hipLaunchKernelGGL(scan_offsets_kernel, dim3(p.frame_count), dim3(kScanThreads), (size_t)p.PB * (2 + parts) * 4, s, p);
 }
+// The chain-server workgroup needs more than the default 64 KB of LDS: the opt-in is per kernel AND per device (a process
+// may hold handles on several GPUs), so it is made once for every (kernel, current device) pair.
+static void allow_srv_lds(const void* kernel)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.insert({kernel, dev}).second)
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSrvLdsBytes);
+}
+
 void launch_fit(const DevParams& p, hipStream_t s)
 {
     const uint32_t grid = p.n_frames * (uint32_t)p.P;
@@ -2286,8 +2302,7 @@ void launch_fit(const DevParams& p, hipStream_t s)
     // with the shortest time per patch; a batch -> the chain-server form, the one with the fewest instructions per point
     if (forced == 2 || (forced == 0 && grid <= 8u * 256u)) { hipLaunchKernelGGL(patch_fit1_kernel<2>, dim3(grid), dim3(2 * kFit1Threads), pad, s, p); return; }
     // chain-server form: persistent workgroups (two fit a CU), each feeder pulls patches until the work counter runs out
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(patch_fit_srv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSrvLdsBytes);
-    (void)once;
+    allow_srv_lds(reinterpret_cast<const void*>(patch_fit_srv_kernel));
     uint32_t wgs = (grid + (uint32_t)kSrvFeeders - 1u) / (uint32_t)kSrvFeeders;
     if (wgs > 2u * 256u) wgs = 2u * 256u;
     hipLaunchKernelGGL(patch_fit_srv_kernel, dim3(wgs), dim3(kWave * (1 + kSrvFeeders)), kSrvLdsBytes, s, p);
@@ -2314,8 +2329,7 @@ void launch_loop_bench(const float* sx, const float* sy, const float* sz, uint8_
     const int w = what >= 64 ? 3 : (what >= 32 ? 2 : 1);      // what + 32: the same loop in the two-wave form, + 64: chain-server form
     what &= 31;
     if (w == 3) {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(srv_loop_bench_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSrvLdsBytes);
-        (void)once;
+        allow_srv_lds(reinterpret_cast<const void*>(srv_loop_bench_kernel));
         const uint32_t wgs = (blocks + (uint32_t)kSrvFeeders - 1u) / (uint32_t)kSrvFeeders;
         hipLaunchKernelGGL(srv_loop_bench_kernel, dim3(wgs), dim3(kWave * (1 + kSrvFeeders)), kSrvLdsBytes, s, sx, sy, sz, mask, il, n, count, what, reps, blocks, out);
         return;
