@@ -156,15 +156,17 @@ rpw_status  rpw_segment_pointcloud2(rpw_handle* h, const uint8_t* data, uint32_t
 /* ---- Host-pointer PIPELINE: the drop-in path with K frames in flight -------------------------------------------
  * Every caller of the reference holds one frame in host memory and calls filterGroundPoints once per frame
  * (reference src/recursive_patchwork_node.cpp:61-108 per PointCloud2 message, src/main.cpp:268,286,
- * test/test_recursive_patchwork.cpp:68,155). rpw_segment is that call, synchronous: one frame's latency (~1.5 ms on
- * an HDL-64 frame, set by its longest sequential add chain) bounds it to a few hundred frames/s. The pipeline keeps
- * K frames in flight instead: every slot owns a HIP stream, pinned staging for the frame and its results, and its own
- * device workspace, so the host copies, the H2D / D2H transfers and the kernels of different slots overlap.
+ * test/test_recursive_patchwork.cpp:68,155). rpw_segment is that call, synchronous: one frame's latency (1 - 5 ms on
+ * HDL-64 frames, set by the longest sequential add chain of its largest patch) bounds it to a few hundred frames/s. The
+ * pipeline keeps K frames in flight instead: every slot owns a HIP stream, pinned staging for the frame and its results,
+ * and its own device workspace, so the host copies and the kernels of different slots overlap.
  *
  *   rpw_set_pipeline(h, K)            K slots (0 frees them); each takes the handle's max_points of capacity
- *   rpw_submit(h, slot, xyz, n, f)    copies the frame into the slot's pinned buffer and enqueues H2D -> kernels ->
- *                                     D2H on the slot's stream; returns at once. RPW_ERR_BUSY if the slot's previous
- *                                     frame has not been waited for. flags: RPW_SUBMIT_RESIDUAL.
+ *   rpw_submit(h, slot, xyz, n, f)    copies the frame into the slot's pinned buffer and enqueues the slot's kernels on
+ *                                     its stream (kernels only: the binning kernel reads the pinned buffer in place, a
+ *                                     copy kernel writes labels / residuals / stats back to pinned memory -- copy-engine
+ *                                     transfers made the slots wait for each other); returns at once. RPW_ERR_BUSY if
+ *                                     the slot's previous frame has not been waited for. flags: RPW_SUBMIT_RESIDUAL.
  *   rpw_slot_input(h, slot)           the slot's pinned input buffer (max_points x 3 floats): a caller that fills it
  *                                     in place and passes it to rpw_submit saves the host copy
  *   rpw_poll(h, slot, &done)          non-blocking: has the slot's frame finished?
