@@ -158,6 +158,24 @@ def gather_records(local_rec, world):
     return out
 
 
+def gather_label_slabs(local_labels, world):
+    """Optional second half of SURVEY.md section 8(e)'s gather: the batch's labels as fixed-size slabs, one per rank, padded to
+    the largest rank's point count (ranks hold different frames) with 0xFF. Returns (slabs [world, slab_bytes], slab_bytes)."""
+    import torch
+    import torch.distributed as dist
+    n = torch.tensor([local_labels.numel()], dtype=torch.int64, device=local_labels.device)
+    if world > 1:
+        dist.all_reduce(n, op=dist.ReduceOp.MAX)
+    slab = int(n.item())
+    mine = torch.full((slab,), 0xFF, dtype=torch.uint8, device=local_labels.device)
+    mine[: local_labels.numel()] = local_labels
+    if world <= 1:
+        return mine.reshape(1, slab), slab
+    out = torch.empty(world * slab, dtype=torch.uint8, device=local_labels.device)
+    dist.all_gather_into_tensor(out, mine)
+    return out.reshape(world, slab), slab
+
+
 def max_over_ranks(elapsed: float, device):
     import torch
     import torch.distributed as dist
@@ -278,6 +296,9 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-path legs and the single-frame latency "
                     "(extra launches of the same kernels: leave them out when rocprofv3 --stats averages should describe the bench batch only)")
     ap.add_argument("--no-profile-events", action="store_true")
+    ap.add_argument("--gather-labels", action="store_true",
+                    help="multi-GPU: after the timed region also all-gather the last batch's label slabs (padded, one per rank) "
+                         "and check them against the gathered records; informational, never part of `value`")
     ap.add_argument("--end-to-end", action="store_true",
                     help="also time the PCIe-inclusive BATCH pipeline (pinned host xyz in, labels back to pinned host memory, "
                          "copies and kernels of consecutive batches overlapped on the streams); reported beside `value`, never as it")
@@ -392,6 +413,19 @@ def main():
         mine = np.stack([st["n_ground"], st["n_zone"] - st["n_ground"], st["n_patches"], st["total_iterations"]], axis=1).astype(np.int32)
         gather_check = {"own_block_equals_stats": bool(np.array_equal(g[0], mine)),
                         "ranks_with_ground_points": int((g[:, :, 0].sum(axis=1) > 0).sum())}
+    if world > 1 and args.gather_labels:
+        # the labels of the last batch this rank computed, as one padded slab per rank (outside the timed region)
+        k_last = (args.steps - 1) % n_streams
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        slabs, slab_bytes = gather_label_slabs(d_labels_all[k_last], world)
+        torch.cuda.synchronize()
+        t_slab = time.perf_counter() - t1
+        if rank == 0:
+            ground_from_labels = (slabs == 1).sum(dim=1).cpu().numpy()
+            ground_from_records = gathered[0].cpu().numpy().reshape(world, F, 4)[:, :, 0].sum(axis=1)
+            gather_check.update({"label_slab_bytes_per_rank": slab_bytes, "label_gather_ms": round(t_slab * 1e3, 3),
+                                 "ground_counts_from_labels_equal_records": bool(np.array_equal(ground_from_labels, ground_from_records))})
     kms = None
     kms_solo = None
     gather_ms = None

@@ -67,7 +67,12 @@ def _gloo_worker(rank, world, port, q):
     rec = _stub_record(rank, frames)
     out = bench.gather_records(rec, world)                   # the result gather of one finished batch
     t = bench.max_over_ranks(0.5 + rank, torch.device("cpu"))
-    q.put((rank, out.tolist(), rec.tolist(), t, [int(rpw_amd.workloads.crc32(f)) for f in frames]))
+    # the optional label slabs: the stub's labels (1 = "ground" of _stub_record), ranks of different sizes -> padded slabs
+    import numpy as np
+    lab = torch.from_numpy(np.concatenate([(f[:, 2] < -1.5).astype(np.uint8) for f in frames])[: 5000 + 1000 * rank].copy())
+    slabs, slab_bytes = bench.gather_label_slabs(lab, world)
+    q.put((rank, out.tolist(), rec.tolist(), t, [int(rpw_amd.workloads.crc32(f)) for f in frames],
+           (slab_bytes, [int((slabs[r] == 1).sum()) for r in range(world)], [int((slabs[r] == 0xFF).sum()) for r in range(world)], int(lab.sum()))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -87,7 +92,9 @@ def test_multi_gpu_result_gather_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, g0, own0, t0, c0), (r1, g1, own1, t1, c1) = res
+    (r0, g0, own0, t0, c0, s0), (r1, g1, own1, t1, c1, s1) = res
+    # label slabs: padded to the larger rank, every rank sees both ranks' labels, the padding is 0xFF
+    assert s0[0] == s1[0] == 6000 and s0[1] == s1[1] == [s0[3], s1[3]] and s0[2] == s1[2] == [1000, 0]
     assert (r0, r1) == (0, 1)
     assert g0 == g1 and len(g0) == world * 3 * 4             # every rank sees every frame's record
     assert g0[:12] == own0 and g0[12:] == own1               # rank order; rank 0 holds rank 1's n_ground and vice versa
