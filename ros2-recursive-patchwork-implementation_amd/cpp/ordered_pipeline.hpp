@@ -9,7 +9,7 @@
 // results leave the buffer in submission order. Same slots, same order, the throughput of the any-order loop.
 #pragma once
 
-#include <deque>
+#include <chrono>
 #include <map>
 #include <thread>
 #include <utility>
@@ -38,7 +38,7 @@ public:
         collect();
         int slot = free_slot();
         while (slot < 0) {                               // every slot busy: wait for whichever finishes first
-            std::this_thread::yield();
+            std::this_thread::sleep_for(std::chrono::microseconds(20));       // (a frame takes milliseconds; no busy spin)
             collect();
             slot = free_slot();
         }
