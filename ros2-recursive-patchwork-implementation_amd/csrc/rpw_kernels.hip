@@ -1556,13 +1556,15 @@ __device__ __attribute__((noinline)) void srv_loop(SrvShared* sv, Fit1Shared* sh
     };
     for (;;) {
         // ---- nothing in flight: wait for a slot (or for the feeders to leave) ----
-        uint32_t idle = 0;
+        // (No limit on the server's own polls: every feeder's waits are bounded, so every feeder leaves, and the server leaves
+        // behind the last of them. A limit here could only fire on feeders that are legitimately busy elsewhere -- the gather
+        // or the radix select of a very large patch.)
         for (;;) {
             const v4u st = *fw;
             const uint32_t done = *donep;
             look(st, cons);
             if (ballot64(ready) != 0ull) break;
-            if (uni(done) >= (uint32_t)kSrvFeeders || ++idle > kSrvSpinLimit) return;
+            if (uni(done) >= (uint32_t)kSrvFeeders) return;
             __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
