@@ -19,12 +19,18 @@
 
 namespace recursive_patchwork {
 
-class OrderedPipeline {
+// (A template on the processor type so that the reorder logic can be tested on a CPU with a scripted stand-in,
+// tests/cpp/test_ordered_pipeline.cpp; OrderedPipeline below is the instance for RecursivePatchwork.)
+template <class Processor>
+class BasicOrderedPipeline {
 public:
     using Result = std::pair<std::vector<Point3D>, std::vector<Point3D>>;
 
     // `rp` must outlive the pipeline; its pipeline depth is set to `slots`, every slot sized for `max_points`
-    OrderedPipeline(RecursivePatchwork& rp, unsigned slots, size_t max_points) : rp_(rp), seq_of_(slots, kFree)
+    // At most `max_held` finished frames wait in the reorder buffer (default 4 x slots): beyond that push() blocks on the
+    // oldest frame in flight instead of refilling slots, so one pathological frame cannot grow the buffer without bound.
+    BasicOrderedPipeline(Processor& rp, unsigned slots, size_t max_points, size_t max_held = 0)
+        : rp_(rp), seq_of_(slots, kFree), cap_(max_held ? max_held : 4 * (size_t)slots)
     {
         rp_.reserve(max_points);
         rp_.setPipelineDepth(slots);
@@ -36,10 +42,17 @@ public:
     {
         std::vector<Result> out;
         collect();
+        deliver(out);
+        while (held_.size() >= cap_) {                   // the buffer is full of frames queued behind the oldest one: wait for THAT one
+            for (size_t s = 0; s < seq_of_.size(); ++s)
+                if (seq_of_[s] == next_out_) { held_.emplace(seq_of_[s], rp_.waitFrame((unsigned)s)); seq_of_[s] = kFree; break; }
+            deliver(out);
+        }
         int slot = free_slot();
         while (slot < 0) {                               // every slot busy: wait for whichever finishes first
             std::this_thread::sleep_for(std::chrono::microseconds(20));       // (a frame takes milliseconds; no busy spin)
             collect();
+            deliver(out);
             slot = free_slot();
         }
         rp_.submitFrame((unsigned)slot, points);
@@ -67,11 +80,10 @@ private:
     void collect()                                        // empty every finished slot into the reorder buffer
     {
         for (size_t s = 0; s < seq_of_.size(); ++s)
-            if (seq_of_[s] != kFree && rp_.frameDone((unsigned)s)) {
+            if (seq_of_[s] != kFree && (seq_of_[s] == next_out_ || held_.size() < cap_) && rp_.frameDone((unsigned)s)) {
                 held_.emplace(seq_of_[s], rp_.waitFrame((unsigned)s));
                 seq_of_[s] = kFree;
             }
-        if (held_.size() > max_held_) max_held_ = held_.size();
     }
     int free_slot() const
     {
@@ -85,12 +97,16 @@ private:
             held_.erase(it);
             ++next_out_;
         }
+        if (held_.size() > max_held_) max_held_ = held_.size();      // frames that really wait (behind an older one)
     }
-    RecursivePatchwork& rp_;
+    Processor& rp_;
     std::vector<unsigned long long> seq_of_;              // slot -> sequence number of the frame it holds
     std::map<unsigned long long, Result> held_;           // finished, not yet deliverable
     unsigned long long next_in_ = 0, next_out_ = 0;
     size_t max_held_ = 0;
+    size_t cap_;
 };
+
+using OrderedPipeline = BasicOrderedPipeline<RecursivePatchwork>;
 
 } // namespace recursive_patchwork

@@ -114,6 +114,16 @@ def test_pointcloud2_io_cpp(tmp_path):
     assert "pointcloud2_io OK" in subprocess.check_output([exe], text=True)
 
 
+def test_ordered_pipeline_cpp(tmp_path):
+    """The reorder logic of cpp/ordered_pipeline.hpp (results in submission order although the slots finish in any order,
+    never more frames on the GPU than slots, a capped reorder buffer) against a scripted stand-in for the engine."""
+    import subprocess
+    exe = str(tmp_path / "ordered")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(rpw_amd.PKG_DIR, "cpp"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_ordered_pipeline.cpp"), "-o", exe])
+    assert "ordered_pipeline OK" in subprocess.check_output([exe], text=True, timeout=120)
+
+
 def test_exact_block_sum_prototype_matches_sequential_sums(tmp_path):
     """tools/proto/exact_block_sum.cpp (groundwork, not product code): the parallel evaluation of a sequential binary32
     sum -- integer prefix sum inside one binade, ties resolved in order, restart behind a binade change -- must equal the
