@@ -251,32 +251,25 @@ def host_path_legs(rpw_amd, cfg_kw, frames, local_rank, seconds=0.8, slots=8):
     dt = time.perf_counter() - t0
     out["any_order"] = {"frames_per_sec": round(done / dt, 1), "latency_ms_median": round(1e3 * float(np.median(lat)), 3),
                         "latency_ms_max": round(1e3 * float(np.max(lat)), 3)}
-    # in order again, but a finished slot is emptied into a host-side reorder buffer and refilled at once; results are
-    # handed on strictly in submission order (what a node that must publish in order can do with the same 8 slots)
-    lat = []; i = 0; done = 0; seq_of = [0] * slots; held = {}; next_out = 0; max_held = 0
+    # in order again, through rpw_amd.OrderedPipeline: a finished slot is emptied into a host-side reorder buffer and
+    # refilled at once; results are handed on strictly in submission order (what a node that must publish in order can do
+    # with the same 8 slots)
+    pipe = rpw_amd.OrderedPipeline(eng, slots=slots)
+    lat = []; t_of = {}; i = 0; done = 0
     t0 = time.perf_counter()
-    for s in range(slots):
-        t_sub[s] = time.perf_counter(); eng.submit(s, base[i % len(base)]); pending[s] = True; seq_of[s] = i; i += 1
-    t_of = {seq_of[s]: t_sub[s] for s in range(slots)}
-    stop = False
-    while any(pending):
-        progressed = False
-        for s in range(slots):
-            if pending[s] and eng.poll(s):
-                buf = np.empty(cap, np.uint8)
-                eng.wait(s, buf); held[seq_of[s]] = buf; pending[s] = False; progressed = True
-                max_held = max(max_held, len(held))
-                while next_out in held:                      # deliver in order
-                    held.pop(next_out); lat.append(time.perf_counter() - t_of.pop(next_out)); next_out += 1; done += 1
-                stop = stop or (time.perf_counter() - t0 >= seconds)
-                if not stop:
-                    t_sub[s] = time.perf_counter(); eng.submit(s, base[i % len(base)]); pending[s] = True
-                    seq_of[s] = i; t_of[i] = t_sub[s]; i += 1
-        if not progressed:
-            time.sleep(0)
+    while time.perf_counter() - t0 < seconds:
+        t_of[i] = time.perf_counter()
+        rs = pipe.push(base[i % len(base)]); i += 1
+        now = time.perf_counter()
+        for _ in rs:
+            lat.append(now - t_of.pop(done)); done += 1
+    rs = pipe.flush()
+    now = time.perf_counter()
+    for _ in rs:
+        lat.append(now - t_of.pop(done)); done += 1
     dt = time.perf_counter() - t0
     out["in_order_reorder_buffer"] = {"frames_per_sec": round(done / dt, 1), "latency_ms_median": round(1e3 * float(np.median(lat)), 3),
-                                      "latency_ms_max": round(1e3 * float(np.max(lat)), 3), "max_finished_frames_held": max_held}
+                                      "latency_ms_max": round(1e3 * float(np.max(lat)), 3), "max_finished_frames_held": pipe.max_held}
     eng.close()
     return out
 

@@ -411,3 +411,69 @@ class RecursivePatchwork:
     def segment(self, points: np.ndarray, want_residual: bool = False):
         """Label array view of the same call (build-side artefact)."""
         return self._engine.segment(points, want_residual)
+
+
+class OrderedPipeline:
+    """Frames in, (labels, residual | None, stats) out IN SUBMISSION ORDER, with up to `slots` frames on the GPU -- the Python
+    twin of cpp/ordered_pipeline.hpp. Waiting on the slots in submission order runs at slots / (latency of the slowest
+    frame); here a finished slot is emptied into a reorder buffer and refilled at once, and results leave the buffer in
+    order: same slots, same order, the throughput of the any-order loop (bench.py, host_path.in_order_reorder_buffer).
+    `engine` needs set_pipeline / submit / poll / wait (rpw_amd.Engine; the CPU test uses a scripted stand-in)."""
+
+    def __init__(self, engine, slots: int = 8, max_held: int | None = None, want_residual: bool = False):
+        self._e = engine
+        self._e.set_pipeline(slots)
+        self._seq = [None] * slots                      # slot -> sequence number of the frame it holds
+        self._held = {}                                 # finished, not yet deliverable
+        self._next_in = 0
+        self._next_out = 0
+        self._cap = max_held if max_held else 4 * slots
+        self._res = want_residual
+        self.max_held = 0
+
+    def frames_on_gpu(self) -> int:
+        return sum(q is not None for q in self._seq)
+
+    def _collect(self):
+        for s, q in enumerate(self._seq):
+            if q is not None and (q == self._next_out or len(self._held) < self._cap) and self._e.poll(s):
+                self._held[q] = self._e.wait(s)
+                self._seq[s] = None
+
+    def _deliver(self, out):
+        while self._next_out in self._held:
+            out.append(self._held.pop(self._next_out))
+            self._next_out += 1
+        self.max_held = max(self.max_held, len(self._held))
+
+    def push(self, xyz) -> list:
+        """Submit one frame (blocks only while every slot is busy); returns the results that became deliverable, oldest first."""
+        import time
+        out = []
+        self._collect()
+        self._deliver(out)
+        while len(self._held) >= self._cap:             # full of frames queued behind the oldest one: wait for that one
+            s = self._seq.index(self._next_out)
+            self._held[self._next_out] = self._e.wait(s)
+            self._seq[s] = None
+            self._deliver(out)
+        while None not in self._seq:                    # every slot busy
+            time.sleep(20e-6)
+            self._collect()
+            self._deliver(out)
+        s = self._seq.index(None)
+        self._e.submit(s, xyz, want_residual=self._res)
+        self._seq[s] = self._next_in
+        self._next_in += 1
+        self._deliver(out)
+        return out
+
+    def flush(self) -> list:
+        """Wait for everything in flight; the remaining results in order."""
+        out = []
+        for s, q in enumerate(self._seq):
+            if q is not None:
+                self._held[q] = self._e.wait(s)
+                self._seq[s] = None
+        self._deliver(out)
+        return out

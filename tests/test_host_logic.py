@@ -114,6 +114,49 @@ def test_pointcloud2_io_cpp(tmp_path):
     assert "pointcloud2_io OK" in subprocess.check_output([exe], text=True)
 
 
+class _ScriptedEngine:
+    """Stand-in for rpw_amd.Engine's pipeline calls: a frame is 'done' after a scripted number of polls of its slot."""
+
+    def __init__(self):
+        self.rs = np.random.RandomState(11)
+        self.slots = []
+        self.max_busy = 0
+
+    def set_pipeline(self, n):
+        self.slots = [None] * n
+
+    def submit(self, s, xyz, want_residual=False):
+        assert self.slots[s] is None
+        self.slots[s] = [int(self.rs.randint(0, 23)), float(xyz[0][0])]
+        self.max_busy = max(self.max_busy, sum(x is not None for x in self.slots))
+
+    def poll(self, s):
+        self.slots[s][0] -= 1
+        return self.slots[s][0] < 0
+
+    def wait(self, s):
+        tag = self.slots[s][1]
+        self.slots[s] = None
+        return (np.array([tag]), None, {})
+
+
+def test_ordered_pipeline_python():
+    """rpw_amd.OrderedPipeline: results in submission order although the slots finish in any order, never more frames in
+    flight than slots, reorder buffer capped."""
+    for slots, cap in ((1, None), (3, None), (8, None), (4, 6)):
+        eng = _ScriptedEngine()
+        pipe = rpw_amd.OrderedPipeline(eng, slots=slots, max_held=cap)
+        got = []
+        for k in range(400):
+            for labels, _, _ in pipe.push(np.array([[float(k), 0.0, 0.0]], np.float32)):
+                got.append(labels[0])
+            assert pipe.frames_on_gpu() <= slots
+        got += [r[0][0] for r in pipe.flush()]
+        assert got == [float(k) for k in range(400)]
+        assert eng.max_busy <= slots and pipe.frames_on_gpu() == 0
+        assert pipe.max_held <= (cap if cap else 4 * slots)
+
+
 def test_ordered_pipeline_cpp(tmp_path):
     """The reorder logic of cpp/ordered_pipeline.hpp (results in submission order although the slots finish in any order,
     never more frames on the GPU than slots, a capped reorder buffer) against a scripted stand-in for the engine."""
