@@ -400,10 +400,12 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, dev)
+    for e in engines:                       # patch_fit's error flag (a chain-server wait timed out) is reported here: raises
+        e.batch_stats(F)
     gather_check = None
     if world > 1 and rank == 0:
         g = gathered[0].cpu().numpy().reshape(world, F, 4)
-        mine = np.stack([st["n_ground"], st["n_zone"] - st["n_ground"], st["n_patches"], st["total_iterations"]], axis=1).astype(np.int32)
+        mine = np.stack([st["n_ground"], st["n_clean"] - st["n_ground"], st["n_patches"], st["total_iterations"]], axis=1).astype(np.int32)
         gather_check = {"own_block_equals_stats": bool(np.array_equal(g[0], mine)),
                         "ranks_with_ground_points": int((g[:, :, 0].sum(axis=1) > 0).sum())}
     if world > 1 and args.gather_labels:

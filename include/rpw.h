@@ -168,7 +168,10 @@ rpw_status  rpw_segment_pointcloud2(rpw_handle* h, const uint8_t* data, uint32_t
  *                                     transfers made the slots wait for each other); returns at once. RPW_ERR_BUSY if
  *                                     the slot's previous frame has not been waited for. flags: RPW_SUBMIT_RESIDUAL.
  *   rpw_slot_input(h, slot)           the slot's pinned input buffer (max_points x 3 floats): a caller that fills it
- *                                     in place and passes it to rpw_submit saves the host copy
+ *                                     in place and passes it to rpw_submit saves the host copy. The pointer stays valid
+ *                                     until rpw_set_pipeline / rpw_set_config / rpw_destroy, or until an
+ *                                     rpw_submit_pointcloud2 on this slot needs more than max_points x 12 bytes and
+ *                                     replaces the buffer (ask again after such a call)
  *   rpw_poll(h, slot, &done)          non-blocking: has the slot's frame finished?
  *   rpw_wait(h, slot, labels, residual, stats)   blocks until the slot's frame is done, copies its results out and
  *                                     frees the slot. Slots complete independently and may be waited in any order.
@@ -223,9 +226,11 @@ rpw_status  rpw_segment_batch_device(rpw_handle* h, const float* d_xyz, const ui
 rpw_status  rpw_get_batch_stats(rpw_handle* h, rpw_frame_stats* stats, uint32_t n_frames);
 
 /* Per-frame result record of the last batch, written on the DEVICE as four int32 per frame -- ground points, non-ground
- * points of the zone, patches, refits (the counts a reference caller sees, recursive_patchwork.cpp:421-423) -- into d_out
+ * points (n_clean - n_ground: the zone's non-ground points plus the cleaned points beyond filtering_radius, i.e. the size
+ * of the reference's non_ground_points, recursive_patchwork.cpp:415-423), patches, refits -- into d_out
  * (device memory, 4 * n_frames int32). Enqueued on `stream` behind the batch (an event dependency if `stream` is not the
- * batch's own): what the multi-GPU result gather sends, with no host round trip. */
+ * batch's own): what the multi-GPU result gather sends, with no host round trip. If the batch ended with patch_fit's
+ * error flag set (the condition rpw_get_batch_stats reports as RPW_ERR_HIP), every field of every record is -1. */
 rpw_status  rpw_result_record_device(rpw_handle* h, int32_t* d_out, uint32_t n_frames, void* stream);
 
 /* Optional recursion-tree trace of the last call (costs a little time; off by default). */

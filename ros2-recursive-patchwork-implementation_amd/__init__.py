@@ -196,6 +196,7 @@ class Engine:
             self._h = C.c_void_p()
             raise RpwError(f"rpw_create failed ({st}): {msg}")
         self.max_points, self.max_frames, self.device = max_points, max_frames, device
+        self._slot_n, self._slot_res = [], []          # pipeline slots (set_pipeline)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -258,6 +259,10 @@ class Engine:
         self._slot_n = [0] * n_slots
         self._slot_res = [False] * n_slots
 
+    def _slot_check(self, slot: int):
+        if not 0 <= int(slot) < len(self._slot_n):
+            raise RpwError(f"slot {slot} does not exist (set_pipeline made {len(self._slot_n)})")
+
     def slot_input(self, slot: int, n: int) -> np.ndarray:
         """The slot's pinned input buffer as an (n, 3) float32 view: fill it and pass it to submit() to skip the host copy."""
         ptr = self._L.rpw_slot_input(self._h, slot)
@@ -268,6 +273,7 @@ class Engine:
     def submit(self, slot: int, xyz: np.ndarray, want_residual: bool = False):
         """Enqueue one frame (host memory) on a pipeline slot; returns at once."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        self._slot_check(slot)
         self._check(self._L.rpw_submit(self._h, slot, xyz.ctypes.data, len(xyz), 1 if want_residual else 0))
         self._slot_n[slot] = len(xyz)
         self._slot_res[slot] = want_residual
@@ -275,6 +281,9 @@ class Engine:
     def submit_pointcloud2(self, slot: int, data: np.ndarray, n: int, point_step: int, off_x: int, off_y: int, off_z: int,
                            want_residual: bool = False):
         data = np.ascontiguousarray(data, dtype=np.uint8)
+        self._slot_check(slot)
+        if data.size < int(n) * int(point_step):
+            raise ValueError(f"submit_pointcloud2: {n} records of {point_step} bytes need {int(n) * int(point_step)} bytes, data holds {data.size}")
         self._check(self._L.rpw_submit_pointcloud2(self._h, slot, data.ctypes.data, n, point_step, off_x, off_y, off_z,
                                                    1 if want_residual else 0))
         self._slot_n[slot] = n
@@ -287,9 +296,15 @@ class Engine:
 
     def wait(self, slot: int, labels: np.ndarray | None = None):
         """Block until the slot's frame is done -> (labels, residual | None, stats dict); frees the slot."""
+        self._slot_check(slot)
         n = self._slot_n[slot]
         if labels is None:
             labels = np.empty(n, np.uint8)
+        elif not (isinstance(labels, np.ndarray) and labels.dtype == np.uint8 and labels.flags.c_contiguous
+                  and labels.flags.writeable and labels.size >= n):
+            # rpw_wait copies n bytes to the pointer it is given: anything else than a writable C-contiguous uint8 array
+            # of at least n elements would be written past its end (or not where the caller looks)
+            raise ValueError(f"wait: labels must be a writable C-contiguous uint8 array of at least {n} elements")
         res = np.empty(n, np.float32) if self._slot_res[slot] else None
         st = CFrameStats()
         self._check(self._L.rpw_wait(self._h, slot, labels.ctypes.data, res.ctypes.data if res is not None else None,
@@ -329,7 +344,7 @@ class Engine:
                                                      d_labels_ptr, d_residual_ptr or None, stream or None))
 
     def result_record_device(self, d_out_ptr: int, n_frames: int, stream: int | None = None):
-        """int32[4 * n_frames] {ground, non-ground in zone, patches, refits} per frame of the last batch, written on the device."""
+        """int32[4 * n_frames] {ground, non-ground (zone + beyond the radius), patches, refits} per frame of the last batch, written on the device."""
         self._check(self._L.rpw_result_record_device(self._h, d_out_ptr, n_frames, stream or None))
 
     def set_debug_gather_only(self, enable: bool):

@@ -78,6 +78,7 @@ public:
     void setPipelineDepth(unsigned depth);
     unsigned pipelineDepth() const { return depth_; }
     void reserve(size_t max_points);                       // capacity of every slot (frames must not grow past it while frames are in flight)
+    size_t capacity() const { return capacity_; }          // points a frame may have without the engine re-allocating (0: no engine yet)
     void submitFrame(unsigned slot, const std::vector<Point3D>& points);
     void submitPointCloud2(unsigned slot, const unsigned char* data, size_t n, unsigned point_step,
                            unsigned off_x, unsigned off_y, unsigned off_z);

@@ -7,7 +7,6 @@
 // beside this file (colcon build --packages-select recursive_patchwork); launch/recursive_patchwork.launch.py mirrors the
 // reference's launch arguments.
 #include <algorithm>
-#include <array>
 #include <chrono>
 #include <memory>
 #include <string>
@@ -18,6 +17,7 @@
 #include <sensor_msgs/msg/point_field.hpp>
 #include <visualization_msgs/msg/marker_array.hpp>
 
+#include "../frame_pipeline.hpp"
 #include "../pointcloud2_io.hpp"
 #include "../recursive_patchwork.hpp"
 
@@ -47,7 +47,13 @@ public:
         config.th_seeds = static_cast<float>(angle_threshold);
         RecursivePatchwork::setDevice(device);
         processor_ = std::make_unique<RecursivePatchwork>(config);            // throws if no MI355X: no CPU fallback
-        if (depth_ > 1) processor_->setPipelineDepth(depth_);
+        // addition: expected points per scan. Every pipeline slot is sized for it up front; a larger scan still works (the
+        // frames in flight are published first, then the engine grows), it only costs that one stall.
+        const int64_t max_points = declare_parameter<int>("max_points", 262144);
+        if (depth_ > 1) {
+            if (max_points > 0) processor_->reserve(static_cast<size_t>(max_points));
+            pipeline_ = std::make_unique<Pipeline>(*processor_, depth_);
+        }
 
         sub_ = create_subscription<sensor_msgs::msg::PointCloud2>(
             input_topic_, rclcpp::SensorDataQoS(),
@@ -121,11 +127,10 @@ private:
                 // the message bytes go to the GPU as they are (no PCL hop, no host repacking)
                 publishFrame(processor_->filterGroundPointCloud2(data, n, L.point_step, L.off_x, L.off_y, L.off_z), msg.header);
             } else {
-                // pipeline: the slot this frame will use still holds the frame submitted depth_ callbacks ago: publish that one first
-                const unsigned slot = static_cast<unsigned>(seq_ % depth_);
-                if (in_flight_[slot]) { publishFrame(processor_->waitFrame(slot), headers_[slot]); in_flight_[slot] = false; }
-                processor_->submitPointCloud2(slot, data, n, L.point_step, L.off_x, L.off_y, L.off_z);
-                headers_[slot] = msg.header; in_flight_[slot] = true; ++seq_;
+                // pipeline (../frame_pipeline.hpp): the slot this frame takes still holds the frame submitted depth_ callbacks
+                // ago, which is published first; a frame beyond the engine's capacity drains the pipeline before it grows
+                pipeline_->push(data, n, L.point_step, L.off_x, L.off_y, L.off_z, msg.header,
+                                [this](const Pipeline::Result& r, const std_msgs::msg::Header& hd) { publishFrame(r, hd); });
             }
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
             RCLCPP_DEBUG(get_logger(), "processed %zu points in %.3f ms", n, ms);
@@ -153,9 +158,8 @@ private:
     std::string input_topic_, ground_topic_, obstacles_topic_, visualization_topic_;
     std::unique_ptr<RecursivePatchwork> processor_;
     unsigned depth_ = 1;
-    uint64_t seq_ = 0;
-    std::array<bool, 32> in_flight_{};
-    std::array<std_msgs::msg::Header, 32> headers_;
+    using Pipeline = BasicFramePipeline<RecursivePatchwork, std_msgs::msg::Header>;
+    std::unique_ptr<Pipeline> pipeline_;
     rclcpp::Subscription<sensor_msgs::msg::PointCloud2>::SharedPtr sub_;
     rclcpp::Publisher<sensor_msgs::msg::PointCloud2>::SharedPtr ground_pub_, obstacles_pub_;
     rclcpp::Publisher<visualization_msgs::msg::MarkerArray>::SharedPtr markers_pub_;

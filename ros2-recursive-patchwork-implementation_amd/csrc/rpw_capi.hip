@@ -602,7 +602,7 @@ rpw_status rpw_result_record_device(rpw_handle* h, int32_t* d_out, uint32_t n_fr
     RPW_HIP(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     if (w.done_valid && s != w.last_stream) RPW_HIP(h, hipStreamWaitEvent(s, w.done_ev, 0));   // behind the batch, whatever the stream
-    launch_result_record(w.d_stats, d_out, n_frames, s);
+    launch_result_record(w.d_stats, d_out, n_frames, w.d_ctrl + kBuckets + 2, s);      // (+ patch_fit's error flag: records of an invalid batch are -1)
     RPW_HIP(h, hipGetLastError());
     return RPW_OK;
 }
@@ -707,6 +707,7 @@ rpw_status rpw_submit(rpw_handle* h, uint32_t slot, const float* xyz, uint32_t n
     if (n > h->max_points) return fail(h, RPW_ERR_CAPACITY, "frame of %u points > capacity %u", n, h->max_points);
     RPW_HIP(h, hipSetDevice(h->device));
     const size_t bytes = (size_t)n * 3 * sizeof(float);
+    if (!s->h_in || bytes > s->h_in_bytes) return fail(h, RPW_ERR_HIP, "slot %u has no staging buffer for %zu bytes", slot, bytes);
     if (n && reinterpret_cast<const unsigned char*>(xyz) != s->h_in) std::memcpy(s->h_in, xyz, bytes);   // filled in place: nothing to copy
     return enqueue_slot(h, s, n, bytes, InputLayout(), (flags & RPW_SUBMIT_RESIDUAL) != 0);
 }
@@ -725,10 +726,18 @@ rpw_status rpw_submit_pointcloud2(rpw_handle* h, uint32_t slot, const uint8_t* d
     if (n > h->max_points) return fail(h, RPW_ERR_CAPACITY, "frame of %u points > capacity %u", n, h->max_points);
     RPW_HIP(h, hipSetDevice(h->device));
     const size_t bytes = (size_t)n * point_step;
-    if (bytes > s->h_in_bytes) {                     // records wider than 12 bytes: the slot's staging grows on demand
-        (void)hipHostFree(s->h_in); s->h_in = nullptr; s->h_in_bytes = 0;
-        RPW_HIP(h, hipHostMalloc((void**)&s->h_in, bytes, hipHostMallocDefault)); s->h_in_bytes = bytes;
+    if (bytes > s->h_in_bytes) {
+        // records wider than 12 bytes: the slot's staging grows on demand. The new buffer is allocated FIRST and swapped in
+        // only on success, so a failed allocation leaves the slot usable (pointers from rpw_slot_input die with the old one)
+        unsigned char* grown = nullptr;
+        RPW_HIP(h, hipHostMalloc((void**)&grown, bytes, hipHostMallocDefault));
+        const bool in_place = data == s->h_in;        // the caller filled the old buffer: its bytes move along
+        if (in_place && s->h_in_bytes) std::memcpy(grown, s->h_in, s->h_in_bytes);
+        if (s->h_in) (void)hipHostFree(s->h_in);
+        s->h_in = grown; s->h_in_bytes = bytes;
+        if (in_place) data = grown;
     }
+    if (!s->h_in) return fail(h, RPW_ERR_HIP, "slot %u has no staging buffer", slot);
     if (bytes && data != s->h_in) std::memcpy(s->h_in, data, bytes);
     InputLayout lay; lay.stride = point_step; lay.off[0] = off_x; lay.off[1] = off_y; lay.off[2] = off_z;
     return enqueue_slot(h, s, n, bytes, lay, (flags & RPW_SUBMIT_RESIDUAL) != 0);

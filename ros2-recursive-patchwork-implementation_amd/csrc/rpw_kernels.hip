@@ -2209,14 +2209,19 @@ __global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void srv_loop_bench_k
 }
 
 // ------------------------------------------------------------------------------------------
-// per-frame result record of a batch, as four int32: ground points, non-ground points of the zone, patches, refits
-// (what the multi-GPU result gather exchanges: reference callers get exactly these counts, recursive_patchwork.cpp:421-423)
-__global__ __launch_bounds__(256) void result_record_kernel(const rpw_frame_stats* __restrict__ stats, int32_t* __restrict__ out, uint32_t n_frames)
+// per-frame result record of a batch, as four int32: ground points, non-ground points (the zone's AND the cleaned points
+// beyond filtering_radius, which the reference appends to non_ground_points: recursive_patchwork.cpp:415-419), patches, refits
+// (what the multi-GPU result gather exchanges: the sizes a reference caller prints, recursive_patchwork.cpp:421-423)
+// If patch_fit's error flag is set (a wave timed out waiting for the chain server: the batch's results are invalid), every
+// field of every record is -1, so that a consumer that only sees the gathered records cannot mistake them for counts.
+__global__ __launch_bounds__(256) void result_record_kernel(const rpw_frame_stats* __restrict__ stats, int32_t* __restrict__ out, uint32_t n_frames,
+                                                            const uint32_t* __restrict__ fit_error)
 {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_frames) return;
+    if (*fit_error) { out[4 * f] = out[4 * f + 1] = out[4 * f + 2] = out[4 * f + 3] = -1; return; }
     const rpw_frame_stats st = stats[f];
-    out[4 * f] = (int32_t)st.n_ground; out[4 * f + 1] = (int32_t)(st.n_zone - st.n_ground);
+    out[4 * f] = (int32_t)st.n_ground; out[4 * f + 1] = (int32_t)(st.n_clean - st.n_ground);
     out[4 * f + 2] = (int32_t)st.n_patches; out[4 * f + 3] = (int32_t)st.total_iterations;
 }
 
@@ -2309,9 +2314,9 @@ void launch_fit(const DevParams& p, hipStream_t s)
     if (wgs > 2u * 256u) wgs = 2u * 256u;
     hipLaunchKernelGGL(patch_fit_srv_kernel, dim3(wgs), dim3(kWave * (1 + kSrvFeeders)), kSrvLdsBytes, s, p);
 }
-void launch_result_record(const rpw_frame_stats* stats, int32_t* out, uint32_t n_frames, hipStream_t s)
+void launch_result_record(const rpw_frame_stats* stats, int32_t* out, uint32_t n_frames, const uint32_t* fit_error, hipStream_t s)
 {
-    if (n_frames) hipLaunchKernelGGL(result_record_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, stats, out, n_frames);
+    if (n_frames) hipLaunchKernelGGL(result_record_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, s, stats, out, n_frames, fit_error);
 }
 void launch_frame_setup(uint32_t* offsets, uint32_t n, uint32_t tiles, uint32_t* ctrl, uint32_t ctrl_words, hipStream_t s)
 {

@@ -21,6 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle_lib as O          # noqa: E402
 import rpw_amd                  # noqa: E402
+from parity_util import nodes_crc   # noqa: E402
 
 CASES = [
     ("c1", 1, {}),
@@ -55,7 +56,7 @@ def run_case(name, seed, kw):
         "labels_crc32": crc(r.labels), "label_hist": np.bincount(r.labels, minlength=4).tolist(),
         "residual_crc32": crc(r.residual),
         "stats": {k: int(v) for k, v in r.stats.items()},
-        "nodes_crc32": crc(nodes[["patch", "depth", "start", "len", "kind", "iterations", "n_inliers", "split_axis"]].copy()),
+        "nodes_crc32": nodes_crc(r.nodes),      # integer fields of the whole recursion tree, field by field (no padding bytes)
         "first_nodes": [{"patch": int(n["patch"]), "len": int(n["len"]), "kind": int(n["kind"]), "iterations": int(n["iterations"]),
                          "centroid": [float(v) for v in n["centroid"]], "normal": [float(v) for v in n["normal"]],
                          "residual": float(n["residual"])} for n in head],

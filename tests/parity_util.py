@@ -25,6 +25,20 @@ def sort_nodes(nodes, with_frame=False):
     return nodes[np.lexsort(keys)]
 
 
+NODE_INT_FIELDS = ("patch", "depth", "start", "len", "kind", "iterations", "n_inliers", "split_axis")
+
+
+def nodes_crc(nodes):
+    """CRC32 of the recursion tree's integer fields, nodes sorted by (patch, start, depth), field by field: a multi-field
+    selection of a structured array keeps its padding, and hashing uninitialised padding bytes is not reproducible."""
+    import zlib
+    s = sort_nodes(nodes)
+    c = 0
+    for f in NODE_INT_FIELDS:
+        c = zlib.crc32(np.ascontiguousarray(s[f]).astype("<i8").tobytes(), c)
+    return c & 0xFFFFFFFF
+
+
 def assert_frame_parity(xyz, labels, residual, stats, nodes, ocfg, check_nodes=True, tag=""):
     """Compare one frame of HIP output with the oracle run on the same input."""
     ref = O.segment(xyz, ocfg, want_residual=residual is not None, want_nodes=check_nodes,

@@ -10,7 +10,7 @@ import pytest
 import oracle_lib as O
 import rpw_amd
 from rpw_amd import workloads as W
-from parity_util import cfg_pair, assert_frame_parity, sort_nodes
+from parity_util import cfg_pair, assert_frame_parity, sort_nodes, nodes_crc
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,10 +30,13 @@ def test_hip_against_golden_fixtures(engine_factory, case):
     if "adaptive_seed_height" in kw:
         kw["adaptive_seed_height"] = bool(kw["adaptive_seed_height"])
     eng = engine_factory(rpw_amd.PatchworkConfig(**kw), max_points=len(xyz), max_frames=1)
+    eng.set_trace(True, max(1 << 16, len(xyz)))
     labels, res, st = eng.segment(xyz, want_residual=True)
     assert crc(labels) == case["labels_crc32"]
     for k, v in case["stats"].items():
         assert int(st[k]) == v, k
+    nodes = eng.nodes(max(1 << 16, len(xyz)))
+    assert len(nodes) == case["stats"]["n_nodes"] and nodes_crc(nodes) == case["nodes_crc32"]      # the whole recursion tree
     # residuals: within 1e-5 of the oracle is the bar; bit equality is expected and reported
     if crc(res) != case["residual_crc32"]:
         ref = O.segment(xyz, O.make_config(**case["config"]), want_nodes=False).residual
@@ -63,7 +66,8 @@ def test_result_record_on_device_and_gather_only_diagnostic(engine_factory):
     """rpw_result_record_device: the per-frame record the multi-GPU gather sends, written behind the batch on ANOTHER
     stream (event dependency), equals the batch stats. The gather-only diagnostic launch leaves the handle usable."""
     import torch
-    frames = [W.c2_hdl64(1), W.c1_test_cloud(2), W.c2_hdl64(2)[::2]]
+    # (the last frame reaches beyond filtering_radius: its outside points belong to the reference's non_ground_points)
+    frames = [W.c2_hdl64(1), W.c1_test_cloud(2), W.c2_hdl64(2)[::2], W.c1_test_cloud(4) * np.array([4, 4, 1], np.float32)]
     off = np.zeros(len(frames) + 1, np.uint32); off[1:] = np.cumsum([len(f) for f in frames])
     pc, oc = cfg_pair(max_split_depth=3)
     eng = engine_factory(pc, max_points=int(off[-1]), max_frames=len(frames))
@@ -80,8 +84,12 @@ def test_result_record_on_device_and_gather_only_diagnostic(engine_factory):
     st = eng.batch_stats(len(frames))
     for f, xyz in enumerate(frames):
         ref = O.segment(xyz, oc, want_residual=False, want_nodes=False)
-        assert got[f].tolist() == [ref.stats["n_ground"], ref.stats["n_zone"] - ref.stats["n_ground"], ref.stats["n_patches"],
-                                   ref.stats["total_iterations"]]
+        # non-ground as the reference returns it (recursive_patchwork.cpp:402-419): size of its second vector
+        _, ng = O.filter_ground_points(xyz, oc)
+        assert got[f].tolist() == [ref.stats["n_ground"], len(ng), ref.stats["n_patches"], ref.stats["total_iterations"]]
+        assert len(ng) == ref.stats["n_clean"] - ref.stats["n_ground"]
+        if f == len(frames) - 1:
+            assert ref.stats["n_clean"] > ref.stats["n_zone"]        # the frame does have points beyond the radius
         assert int(st["n_ground"][f]) == ref.stats["n_ground"]
     eng.set_debug_gather_only(True)
     eng.segment_batch_device(d_xyz.data_ptr(), off, d_lab.data_ptr(), None, s_batch.cuda_stream)

@@ -167,6 +167,19 @@ def test_ordered_pipeline_cpp(tmp_path):
     assert "ordered_pipeline OK" in subprocess.check_output([exe], text=True, timeout=120)
 
 
+def test_node_frame_pipeline_cpp(tmp_path):
+    """cpp/frame_pipeline.hpp, the ROS2 node's frame pipeline, on a scripted engine with RecursivePatchwork's capacity rule
+    (no growing while frames are in flight): a short first scan followed by full scans, a larger scan into a full pipeline
+    and a failing wait must neither lose nor reorder the other frames."""
+    import subprocess
+    exe = str(tmp_path / "frame_pipeline")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(rpw_amd.PKG_DIR, "cpp"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_frame_pipeline.cpp"), "-o", exe])
+    assert "frame_pipeline OK" in subprocess.check_output([exe], text=True, timeout=120)
+    node_src = open(os.path.join(rpw_amd.PKG_DIR, "cpp", "ros2", "recursive_patchwork_node.cpp")).read()
+    assert "BasicFramePipeline<RecursivePatchwork" in node_src and "pipeline_->push(" in node_src      # the node uses it
+
+
 def test_exact_block_sum_prototype_matches_sequential_sums(tmp_path):
     """tools/proto/exact_block_sum.cpp (groundwork, not product code): the parallel evaluation of a sequential binary32
     sum -- integer prefix sum inside one binade, ties resolved in order, restart behind a binade change -- must equal the

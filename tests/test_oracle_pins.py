@@ -15,6 +15,7 @@ import pytest
 import oracle_lib as O
 import np_emulation as E
 import rpw_amd
+from parity_util import nodes_crc
 
 W = rpw_amd.workloads
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -37,6 +38,7 @@ def test_golden(case):
     assert crc(r.residual) == case["residual_crc32"]
     for k, v in case["stats"].items():
         assert int(r.stats[k]) == v, k
+    assert len(r.nodes) == r.stats["n_nodes"] and nodes_crc(r.nodes) == case["nodes_crc32"]      # the whole recursion tree
     nodes = r.nodes[np.lexsort([r.nodes["depth"], r.nodes["start"], r.nodes["patch"]])]
     for got, want in zip(nodes[:4], case["first_nodes"]):
         assert int(got["patch"]) == want["patch"] and int(got["iterations"]) == want["iterations"]
