@@ -37,7 +37,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_POINT_FIT = 17        # 12 sorted xyz + 4 index + 1 label
 BYTES_PER_POINT_BIN = 28        # 12 xyz in + 12 sorted SoA out + 4 index out
-PROFILE_ROUND = "r02"
+BYTES_PER_POINT_BIN_ACTUAL = 40 # what the counting sort moves: the input is read twice (count pass, scatter pass)
+PROFILE_ROUND = "r03"
 
 
 WORKLOADS = {   # name: (generator, config, default frames per step, description) -- BASELINE.json `configs`
@@ -283,6 +284,8 @@ def main():
                     help="c2 (default) is the configuration the metric is quoted on; the others are informational")
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (one batch); 0 = the workload's default (c2: 512)")
     ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (HIP streams, one engine each)")
+    ap.add_argument("--regions", type=int, default=0, help="timed regions of --steps steps each (value = the median region); "
+                    "0 = as many as it takes to measure about one second, 1 = a single region")
     ap.add_argument("--max-iter", type=int, default=100,
                     help="refit iterations; 0 = SURVEY.md 8d 'variant B' (every fit ends at once, so the recursion is forced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -389,17 +392,26 @@ def main():
         for e in engines:
             e.set_profiling(True)
             e.kernel_ms(reset=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dev)
+    def timed_region():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; seconds, the maximum over the ranks"""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return max_over_ranks(time.perf_counter() - t0, dev)
+
+    # The region is repeated until about a second of GPU time has been measured (a 20-step region lasts ~0.1 s: too short
+    # to be insensitive to clock ramp); `value` is quoted on the MEDIAN region, the spread is reported beside it.
+    regions = [timed_region()]
+    n_regions = 1 if args.regions == 1 else (args.regions if args.regions > 1 else max(1, min(64, int(np.ceil(1.0 / max(regions[0], 1e-4))))))
+    while len(regions) < n_regions:
+        regions.append(timed_region())
+    elapsed = float(np.median(regions))
     for e in engines:                       # patch_fit's error flag (a chain-server wait timed out) is reported here: raises
         e.batch_stats(F)
     gather_check = None
@@ -410,7 +422,7 @@ def main():
                         "ranks_with_ground_points": int((g[:, :, 0].sum(axis=1) > 0).sum())}
     if world > 1 and args.gather_labels:
         # the labels of the last batch this rank computed, as one padded slab per rank (outside the timed region)
-        k_last = (args.steps - 1) % n_streams
+        k_last = (step_no[0] - 1) % n_streams
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         slabs, slab_bytes = gather_label_slabs(d_labels_all[k_last], world)
@@ -423,7 +435,6 @@ def main():
                                  "ground_counts_from_labels_equal_records": bool(np.array_equal(ground_from_labels, ground_from_records))})
     kms = None
     kms_solo = None
-    gather_ms = None
     if not args.no_profile_events:
         kms = {}
         for e in engines:
@@ -439,18 +450,7 @@ def main():
             eng.segment_batch_device(d_xyz.data_ptr(), offsets, d_labels.data_ptr(), None, stream.cuda_stream)
         torch.cuda.synchronize()
         kms_solo = eng.kernel_ms(reset=True)
-        # ... and the per-patch compaction that completes the binning pass (patch_fit's gather prologue), by a
-        # diagnostic launch that stops behind it
-        eng.set_debug_gather_only(True)
-        for _ in range(3):
-            eng.segment_batch_device(d_xyz.data_ptr(), offsets, d_labels.data_ptr(), None, stream.cuda_stream)
-        torch.cuda.synchronize()
-        g = eng.kernel_ms(reset=True)
-        gather_ms = g["patch_fit"][0] / max(1, g["patch_fit"][1])
-        eng.set_debug_gather_only(False)
         eng.set_profiling(False)
-        eng.segment_batch_device(d_xyz.data_ptr(), offsets, d_labels.data_ptr(), None, stream.cuda_stream)   # labels valid again
-        torch.cuda.synchronize()
 
     # latency of ONE frame, device-resident (batch of 1), over the 8 distinct frames
     lat = None
@@ -524,6 +524,10 @@ def main():
                     "host_path": "rpw_segment (sync) and rpw_submit / rpw_wait (pipeline): host pointers, one frame per call"},
             "ms_per_frame": round(1e3 * elapsed / (F * args.steps), 5),
             "timed_region_s": round(elapsed, 3),
+            "timed_regions": {"n": len(regions), "steps_each": args.steps, "s_min": round(min(regions), 4), "s_max": round(max(regions), 4),
+                              "total_s": round(sum(regions), 3), "value_is": "frames of one region / median region time",
+                              "frames_per_sec_min": round(F * world * args.steps / max(regions), 1),
+                              "frames_per_sec_max": round(F * world * args.steps / min(regions), 1)},
             # what the recursion did on this workload (a zero here means the headline batch never splits)
             "recursion": {"n_splits_per_frame_mean": round(float(st["n_splits"].mean()), 3),
                           "frames_with_splits": int((st["n_splits"] > 0).sum()),
@@ -547,8 +551,8 @@ def main():
             bpp = BYTES_PER_POINT_FIT if dom == "patch_fit" else BYTES_PER_POINT_BIN
             ach = bpp * total_pts / avg_s / 1e9
             # (a batch runs patch_fit's chain-server kernel; the other two forms are patch_fit1_kernel<1|2>)
-            knames = {"patch_fit": ("patch_fit_srv_kernel", "patch_fit1_kernel"), "bin_tile": ("bin_tile_kernel",),
-                      "scan_offsets": ("scan_offsets_kernel",)}[dom]
+            knames = {"patch_fit": ("patch_fit_srv_kernel", "patch_fit1_kernel"), "bin_count": ("bin_count_kernel",),
+                      "bin_scatter": ("bin_scatter_kernel",), "scan_offsets": ("scan_offsets_kernel",)}[dom]
             traffic, traffic_src = None, None
             for kname in knames:
                 traffic, traffic_src = load_pmc_traffic(kname, F)
@@ -565,7 +569,7 @@ def main():
                                        "launch in the timed region, where launches_in_flight launches share the chip."}
             # what the memory system moves per step (L2-miss traffic of the three kernels from the PMC passes) over the
             # step time: how far the whole pipeline is from HBM's 8 TB/s
-            t_all = [load_pmc_traffic(k, F)[0] for k in ("bin_tile_kernel", "scan_offsets_kernel")] + [traffic if dom == "patch_fit" else None]
+            t_all = [load_pmc_traffic(k, F)[0] for k in ("bin_count_kernel", "scan_offsets_kernel", "bin_scatter_kernel")] + [traffic if dom == "patch_fit" else None]
             if all(t is not None for t in t_all):
                 step_s = elapsed / args.steps
                 rate = sum(t_all) / step_s / 1e9
@@ -575,7 +579,7 @@ def main():
                                         # what this chip streams from HBM at full occupancy (tools/microbench_loads.hip,
                                         # profiles/r02_microbench_loads.txt: 6.24-6.29 TB/s)
                                         "frac_of_measured_streaming_rate": round(rate / 6260.0, 4),
-                                        "note": "FETCH_SIZE x2 + WRITE_SIZE of bin_tile + scan_offsets + patch_fit per launch "
+                                        "note": "FETCH_SIZE x2 + WRITE_SIZE of bin_count + scan_offsets + bin_scatter + patch_fit per launch "
                                                 "(requests that leave L2; Infinity Cache hits are included) / time per step"}
             # the bound that governs patch_fit: sequential binary32 adds. A dependent v_add_f32 retires every
             # 3.4 ns (8.2 cycles, tools/microbench_chain.hip); the chip tops out at 256 CUs x 8 chains / 3.4 ns.
@@ -587,31 +591,28 @@ def main():
                                      "frac": round(chain_rate / chain_peak, 4),
                                      "addends_per_frame": chain_addends_per_batch // F}
             solo = {k: kms_solo[k][0] / max(1, kms_solo[k][1]) for k in kms_solo}
-            bin_s = (solo["bin_tile"] + solo["scan_offsets"]) * 1e-3
+            bin_kernels = ("bin_count", "scan_offsets", "bin_scatter")
+            bin_s = sum(solo[k] for k in bin_kernels) * 1e-3
             achb = BYTES_PER_POINT_BIN * total_pts / bin_s / 1e9
-            tb1, tsrc1 = load_pmc_traffic("bin_tile_kernel", F)
-            tb2, _ = load_pmc_traffic("scan_offsets_kernel", F)
-            full_s = bin_s + gather_ms * 1e-3
-            out["roofline_binning"] = {"kernels": "bin_tile+scan_offsets", "bound": "hbm",
+            tb = [load_pmc_traffic(k + "_kernel", F) for k in bin_kernels]
+            # the WHOLE binning pass of north_star ("radial-sector scatter + per-bin prefix-sum compaction"): a stable counting
+            # sort by patch -- count, scan, scatter -- that leaves every patch contiguous, in input order
+            out["roofline_binning"] = {"kernels": "+".join(bin_kernels), "bound": "hbm",
                                        "measured": "one stream, right after the timed region (in it these kernels queue "
                                                    "behind other streams' patch_fit waves: see in_timed_region_ms)",
                                        "ms_per_launch": round(bin_s * 1e3, 4),
-                                       "in_timed_region_ms": round(per["bin_tile"] + per["scan_offsets"], 4),
+                                       "ms_per_kernel": {k: round(solo[k], 4) for k in bin_kernels},
+                                       "in_timed_region_ms": round(sum(per[k] for k in bin_kernels), 4),
                                        "achieved": round(achb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(achb / HBM_PEAK_GBS, 5),
-                                       "traffic": None if tb1 is None or tb2 is None else tb1 + tb2,
-                                       "traffic_source": tsrc1,
+                                       "traffic": None if any(t[0] is None for t in tb) else sum(t[0] for t in tb),
+                                       "traffic_source": tb[0][1],
                                        "algorithmic_bytes_per_point": BYTES_PER_POINT_BIN,
                                        "algorithmic_bytes_per_launch": BYTES_PER_POINT_BIN * total_pts,
-                                       # the WHOLE binning pass of north_star: + the per-patch compaction (patch_fit's gather prologue)
-                                       "with_per_patch_compaction": {
-                                           "kernels": "bin_tile+scan_offsets+patch_fit(gather prologue only, diagnostic launch)",
-                                           "gather_ms_per_launch": round(gather_ms, 4),
-                                           "ms_per_launch": round(full_s * 1e3, 4),
-                                           "achieved": round(BYTES_PER_POINT_BIN * total_pts / full_s / 1e9, 2),
-                                           "frac": round(BYTES_PER_POINT_BIN * total_pts / full_s / 1e9 / HBM_PEAK_GBS, 5),
-                                           "actual_bytes_per_point": "12 read + 16 written (tile-sorted records) + 16 read + 16 written (patch-sorted SoA + index)",
-                                           "frac_of_actual_bytes": round(60 * total_pts / full_s / 1e9 / HBM_PEAK_GBS, 5)}}
+                                       "actual_bytes_per_point": f"{BYTES_PER_POINT_BIN_ACTUAL}: 12 read (count pass) + 12 read again + 16 written (scatter pass)",
+                                       "frac_of_actual_bytes": round(BYTES_PER_POINT_BIN_ACTUAL * total_pts / bin_s / 1e9 / HBM_PEAK_GBS, 5),
+                                       "previous_design": "rounds 1-2: one pass to tile-sorted records (28 B/pt) + a gather inside patch_fit "
+                                                          "(32 B/pt): 0.36 + 0.68 ms per 512-frame launch, 22 % of peak for the whole pass"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, cfg_kw)
         print(json.dumps(out), flush=True)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define RPW_ABI_VERSION 2
+#define RPW_ABI_VERSION 3
 
 typedef enum rpw_status {
     RPW_OK              = 0,
@@ -116,10 +116,11 @@ typedef struct rpw_handle rpw_handle;
 
 /* kernels timed by rpw_set_profiling / rpw_get_kernel_ms */
 enum {
-    RPW_K_BIN   = 0,   /* classify + stable tile-local sort (binning pass, with RPW_K_SCAN) */
-    RPW_K_SCAN  = 1,   /* per-frame offsets                                                 */
-    RPW_K_FIT   = 2,   /* per-patch gather + recursive plane fit                            */
-    RPW_K_COUNT = 3
+    RPW_K_BIN_COUNT   = 0,   /* binning pass 1/3: classify, per-tile class counts, frame class totals          */
+    RPW_K_SCAN        = 1,   /* binning pass 2/3: per-frame scan -> patch begins, destination of every tile run */
+    RPW_K_BIN_SCATTER = 2,   /* binning pass 3/3: classify, stable rank, write the patch-sorted arrays          */
+    RPW_K_FIT         = 3,   /* recursive plane fit of every patch                                              */
+    RPW_K_COUNT       = 4
 };
 
 void        rpw_default_config(rpw_config* cfg);
@@ -245,9 +246,6 @@ rpw_status  rpw_get_kernel_ms(rpw_handle* h, double ms[RPW_K_COUNT], uint64_t la
  * evaluated on the DEVICE over arrays held in host memory. */
 rpw_status  rpw_debug_angles(rpw_handle* h, const float* x, const float* y, float* angle, uint32_t n);
 rpw_status  rpw_debug_eig3(rpw_handle* h, const float* cov9, float* normal3, uint32_t n);
-/* Diagnostic: with enable != 0 the plane-fit kernel stops behind its gather prologue (the per-patch compaction that
- * completes the binning pass), so that pass can be timed on its own. Labels are not produced in that mode. */
-rpw_status  rpw_set_debug_gather_only(rpw_handle* h, int enable);
 /* Micro-benchmark of the two loops the plane-fit kernel lives in, on a synthetic node of n slots of which inlier_pct %
  * are inliers, one node per workgroup, `blocks` workgroups, `reps` passes each: what = 0..5 chain sweeps (centroid,
  * covariance, residual, range, xy, variance), 16..18 fused / mask passes (seed, plane, older); + 32: the same loop in the

@@ -25,8 +25,8 @@ ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("RPW_LIB", os.path.join(PKG_DIR, "librpw_hip.so"))
 
 LABEL_NONGROUND, LABEL_GROUND, LABEL_DROPPED, LABEL_OUTSIDE, LABEL_EGO = 0, 1, 2, 3, 4
-K_BIN, K_SCAN, K_FIT, K_COUNT = 0, 1, 2, 3
-KERNEL_NAMES = ("bin_tile", "scan_offsets", "patch_fit")
+K_BIN_COUNT, K_SCAN, K_BIN_SCATTER, K_FIT, K_COUNT = 0, 1, 2, 3, 4
+KERNEL_NAMES = ("bin_count", "scan_offsets", "bin_scatter", "patch_fit")
 
 
 class RpwError(RuntimeError):
@@ -149,8 +149,6 @@ def load_library():
     L.rpw_get_batch_stats.restype = i32
     L.rpw_result_record_device.argtypes = [vp, vp, u32, vp]
     L.rpw_result_record_device.restype = i32
-    L.rpw_set_debug_gather_only.argtypes = [vp, i32]
-    L.rpw_set_debug_gather_only.restype = i32
     L.rpw_set_trace.argtypes = [vp, i32, u32]
     L.rpw_set_trace.restype = i32
     L.rpw_get_nodes.argtypes = [vp, vp, u32, C.POINTER(u32)]
@@ -177,7 +175,7 @@ EXPORTED_SYMBOLS = (
     "rpw_submit", "rpw_submit_pointcloud2", "rpw_poll", "rpw_wait", "rpw_set_sensors", "rpw_segment_fused",
     "rpw_segment_batch_device_fused", "rpw_segment_batch_device", "rpw_get_batch_stats", "rpw_set_trace",
     "rpw_get_nodes", "rpw_set_profiling", "rpw_get_kernel_ms", "rpw_debug_angles", "rpw_debug_eig3",
-    "rpw_debug_angles_host", "rpw_debug_loop_bench", "rpw_result_record_device", "rpw_set_debug_gather_only",
+    "rpw_debug_angles_host", "rpw_debug_loop_bench", "rpw_result_record_device",
 )
 
 
@@ -346,9 +344,6 @@ class Engine:
     def result_record_device(self, d_out_ptr: int, n_frames: int, stream: int | None = None):
         """int32[4 * n_frames] {ground, non-ground (zone + beyond the radius), patches, refits} per frame of the last batch, written on the device."""
         self._check(self._L.rpw_result_record_device(self._h, d_out_ptr, n_frames, stream or None))
-
-    def set_debug_gather_only(self, enable: bool):
-        self._check(self._L.rpw_set_debug_gather_only(self._h, int(enable)))
 
     def batch_stats(self, n_frames: int) -> np.ndarray:
         out = np.zeros(n_frames, STATS_DTYPE)

@@ -47,8 +47,6 @@ struct Workspace {
     uint32_t* d_ctrl = nullptr;          // [kBuckets] bucket counts + [1] node count (+pad), then [F][PB] class totals of every frame
     uint32_t* d_bucket_list = nullptr;
     float *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr, *d_ax = nullptr, *d_ay = nullptr, *d_az = nullptr;
-    float4* d_tp = nullptr;
-    uint32_t* d_tdir = nullptr;
     uint32_t* d_sidx = nullptr;
     uint8_t* d_mask = nullptr;
     rpw_frame_stats* d_stats = nullptr;
@@ -94,8 +92,6 @@ struct rpw_handle {
     Workspace ws;                        // batch / one-frame calls
     std::vector<Slot*> slots;            // host-pointer pipeline
 
-    int debug_gather_only = 0;
-
     // trace
     int trace = 0;
     uint32_t nodes_cap = 0;
@@ -113,8 +109,8 @@ struct rpw_handle {
     int profiling = 0;
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> free_events;
-    double ms[RPW_K_COUNT] = {0, 0, 0};
-    uint64_t launches[RPW_K_COUNT] = {0, 0, 0};
+    double ms[RPW_K_COUNT] = {};
+    uint64_t launches[RPW_K_COUNT] = {};
 };
 
 namespace {
@@ -136,7 +132,7 @@ void free_workspace(Workspace& w)
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(w.d_offsets); F(w.d_hist); F(w.d_patch_begin); F(w.d_patches);
     F(w.d_ctrl); F(w.d_bucket_list); F(w.d_sx); F(w.d_sy); F(w.d_sz); F(w.d_ax); F(w.d_ay); F(w.d_az);
-    F(w.d_sidx); F(w.d_mask); F(w.d_tp); F(w.d_tdir); F(w.d_stats);
+    F(w.d_sidx); F(w.d_mask); F(w.d_stats);
     for (int i = 0; i < kStageSlots; ++i) {
         if (w.h_offsets[i]) { (void)hipHostFree(w.h_offsets[i]); w.h_offsets[i] = nullptr; }
         if (w.stage_ev[i]) { (void)hipEventDestroy(w.stage_ev[i]); w.stage_ev[i] = nullptr; }
@@ -252,10 +248,6 @@ rpw_status alloc_workspace(rpw_handle* h, Workspace& w, size_t N, size_t F)
     RPW_HIP(h, hipMalloc(&w.d_ay, N * sizeof(float)));
     RPW_HIP(h, hipMalloc(&w.d_az, N * sizeof(float)));
     RPW_HIP(h, hipMalloc(&w.d_sidx, N * sizeof(uint32_t)));
-    {   // tile-sorted records: slot < frame offset + frame size, so N records suffice
-        RPW_HIP(h, hipMalloc(&w.d_tp, N * sizeof(float4)));
-        RPW_HIP(h, hipMalloc(&w.d_tdir, (size_t)w.max_tiles * h->PB * sizeof(uint32_t)));
-    }
     RPW_HIP(h, hipMalloc(&w.d_mask, N));
     RPW_HIP(h, hipMalloc(&w.d_stats, F * sizeof(rpw_frame_stats)));
     return RPW_OK;
@@ -349,14 +341,11 @@ void fill_params(rpw_handle* h, Workspace& w, DevParams& p, const void* d_xyz, u
     p.sensor_off = w.d_offsets + 2 * (F + 1); p.residual = d_residual;
     p.hist = w.d_hist; p.ftot = w.d_ctrl + kBuckets + 4; p.patch_begin = w.d_patch_begin; p.patches = w.d_patches;
     p.bucket_count = w.d_ctrl; p.bucket_list = w.d_bucket_list; p.list_stride = w.max_frames * (uint32_t)h->P;
-    p.tp = w.d_tp; p.tdir = w.d_tdir;
     p.sx = w.d_sx; p.sy = w.d_sy; p.sz = w.d_sz; p.sidx = w.d_sidx; p.ax = w.d_ax; p.ay = w.d_ay; p.az = w.d_az;
     p.mask = w.d_mask; p.stats = w.d_stats;
     // the trace buffer belongs to the handle: only its own workspace writes it
     const bool tracing = (&w == &h->ws) && h->trace && h->d_nodes;
     p.trace = tracing ? 1 : 0; p.nodes = tracing ? h->d_nodes : nullptr; p.node_count = w.d_ctrl + kBuckets; p.work = w.d_ctrl + kBuckets + 1; p.nodes_cap = tracing ? h->nodes_cap : 0;
-    p.gather_only = h->debug_gather_only;
-
 }
 
 rpw_status run_batch(rpw_handle* h, Workspace& w, const void* d_xyz, const uint32_t* frame_offsets, uint32_t n_frames,
@@ -423,11 +412,10 @@ rpw_status run_batch(rpw_handle* h, Workspace& w, const void* d_xyz, const uint3
     DevParams p;
     fill_params(h, w, p, d_xyz, F, tiles, d_labels, d_residual, lay, ns);
 
-    // ---- binning pass: K1 and K2 once over the whole batch, then K3 ---------------------------------------------
-    // (A variant that cut large batches into groups of frames and pipelined K1 / K2 over two streams, so that K3
-    // would find the xyz still in the Infinity Cache, was measured slower -- launch-bound -- and removed.)
-    timed(h, RPW_K_BIN, stream, [&] { launch_bin(p, stream); });
+    // ---- binning pass (count, scan, scatter: a stable counting sort by patch) once over the whole batch, then the fit ----
+    timed(h, RPW_K_BIN_COUNT, stream, [&] { launch_bin_count(p, stream); });
     timed(h, RPW_K_SCAN, stream, [&] { launch_scan(p, stream); });
+    timed(h, RPW_K_BIN_SCATTER, stream, [&] { launch_bin_scatter(p, stream); });
     timed(h, RPW_K_FIT, stream, [&] { launch_fit(p, stream); });
     RPW_HIP(h, hipGetLastError());
     RPW_HIP(h, hipEventRecord(w.done_ev, stream));
@@ -470,8 +458,9 @@ rpw_status enqueue_slot(rpw_handle* h, Slot* s, uint32_t n, size_t bytes, const 
     DevParams p;
     fill_params(h, w, p, s->h_in, 1, tiles, s->d_labels, want_residual ? s->d_res : nullptr, lay, 0);
     p.trace = 0; p.nodes = nullptr; p.nodes_cap = 0;
-    timed(h, RPW_K_BIN, st, [&] { launch_bin(p, st); });
+    timed(h, RPW_K_BIN_COUNT, st, [&] { launch_bin_count(p, st); });
     timed(h, RPW_K_SCAN, st, [&] { launch_scan(p, st); });
+    timed(h, RPW_K_BIN_SCATTER, st, [&] { launch_bin_scatter(p, st); });
     timed(h, RPW_K_FIT, st, [&] { launch_fit(p, st); });
     launch_frame_copy_out(s->d_labels, s->h_labels, n, want_residual ? s->d_res : nullptr, s->h_res, w.d_stats, s->h_stats, w.d_ctrl + kBuckets + 2, st);
     RPW_HIP(h, hipGetLastError());
@@ -604,13 +593,6 @@ rpw_status rpw_result_record_device(rpw_handle* h, int32_t* d_out, uint32_t n_fr
     if (w.done_valid && s != w.last_stream) RPW_HIP(h, hipStreamWaitEvent(s, w.done_ev, 0));   // behind the batch, whatever the stream
     launch_result_record(w.d_stats, d_out, n_frames, w.d_ctrl + kBuckets + 2, s);      // (+ patch_fit's error flag: records of an invalid batch are -1)
     RPW_HIP(h, hipGetLastError());
-    return RPW_OK;
-}
-
-rpw_status rpw_set_debug_gather_only(rpw_handle* h, int enable)
-{
-    if (!h) return RPW_ERR_INVALID;
-    h->debug_gather_only = enable ? 1 : 0;
     return RPW_OK;
 }
 

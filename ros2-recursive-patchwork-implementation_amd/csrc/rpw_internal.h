@@ -16,7 +16,7 @@ constexpr int kWavePoints  = kWave * kTileItems;  // 512: one wave owns a contig
 constexpr int kMaxSectors  = 128;
 constexpr int kMaxSensors  = 8;                   // LidarFusion pre-step: sensors per frame
 constexpr int kBuckets     = 64;                  // patch-size buckets for largest-first launch order
-constexpr int kGatherTiles = 1024;                // frames of up to 2.1 M points: patch_fit scans its run directory in LDS
+constexpr int kRingFloats  = 2048;                // LDS floats of a patch owner's addend ring (sweeps, fused pass)
 constexpr int kStackDepth  = 48;                  // explicit recursion stack (smaller child first => <= log2(n)+2)
 
 struct PatchDesc {
@@ -56,8 +56,8 @@ struct DevParams {
     uint8_t*  labels;
     float*    residual;           // may be null
 
-    uint32_t* hist;               // [n_tiles][PB]: run length of every class inside the tile (frames of more than
-                                  // kGatherTiles tiles: turned into frame-relative offsets by scan_offsets)
+    uint32_t* hist;               // [n_tiles][PB]: the tile's points of every class (bin_tile's counting pass), turned by
+                                  // scan_offsets into the frame-relative first slot of that run in the patch-sorted arrays
     uint32_t* ftot;               // [F][PB] points of every class in the frame (bin_tile adds its tile's counts; zeroed per batch)
     uint32_t* patch_begin;        // [F][P+1], frame-relative
     PatchDesc* patches;           // [F*P]
@@ -65,10 +65,7 @@ struct DevParams {
     uint32_t* bucket_list;        // [kBuckets][list_stride]
     uint32_t  list_stride;
 
-    float4* tp;                   // TILE-sorted records (x, y, z, original index as bits): inside every tile's
-                                  // 2048-slot region the points are grouped by patch, input order kept
-    uint32_t* tdir;               // [n_tiles][PB] start of every class's run inside its tile
-    float *sx, *sy, *sz;          // patch-sorted SoA (assembled by patch_fit's gather)
+    float *sx, *sy, *sz;          // patch-sorted SoA, input order inside a patch (written by bin_tile's scatter pass)
     uint32_t* sidx;               // original index inside the frame, per slot (never permuted)
     float *ax, *ay, *az;          // scratch for the stable partition
     uint8_t* mask;                // per slot: bit0 = current inlier mask, bit1 = previous mask
@@ -79,10 +76,10 @@ struct DevParams {
     uint32_t* work;               // [0] work counter of patch_fit's chain-server form, [1] its error flag (zeroed with the bucket counts)
     uint32_t  nodes_cap;
     int       trace;
-    int       gather_only;        // diagnostic (rpw_set_debug_gather_only): patch_fit stops behind its gather prologue
 };
 
-void launch_bin(const DevParams& p, hipStream_t s);
+void launch_bin_count(const DevParams& p, hipStream_t s);
+void launch_bin_scatter(const DevParams& p, hipStream_t s);
 void launch_scan(const DevParams& p, hipStream_t s);
 void launch_fit(const DevParams& p, hipStream_t s);
 void launch_frame_setup(uint32_t* offsets, uint32_t n, uint32_t tiles, uint32_t* ctrl, uint32_t ctrl_words, hipStream_t s);

@@ -1,13 +1,13 @@
 // rpw_kernels.hip -- hand-written gfx950 kernels of the Recursive Patchwork hot path.
 //
 //   K1 bin_tile        cleanPoints + computeDistances2D + filterPointsByRadius + computeAngles +
-//                      patch membership (recursive_patchwork.cpp:315-378), O(N) instead of O(P*N),
-//                      and a stable tile-local sort: points grouped by patch inside each 2048-point tile
-//                      (+ the frame's class totals, added up tile by tile with integer atomics)
-//   K2 scan_offsets    per frame: one scan over the classes -> patch begins, patch descriptors, size-bucket lists
-//                      (frames of more than kGatherTiles tiles: also the tile-order offsets of every run)
-//   K3 patch_fit       scan of the patch's run lengths + gather of its runs (recursive_patchwork.cpp:372-378:
-//                      patch_points in zone order), then fitPlaneAndSplit / fitPlanePCA / computeCentroid / computeCovariance /
+//                      patch membership (recursive_patchwork.cpp:315-378), O(N) instead of O(P*N), as a stable counting
+//                      sort by patch in two launches around K2: PASS 0 counts every tile's classes (+ the frame's class
+//                      totals, integer atomics), PASS 1 ranks the tile's points and writes them straight to their final,
+//                      patch-sorted slots (recursive_patchwork.cpp:372-378: patch_points in zone order)
+//   K2 scan_offsets    per frame: one scan over the classes -> patch begins, patch descriptors, size-bucket lists, and the
+//                      first destination slot of every (tile, class)
+//   K3 patch_fit       fitPlaneAndSplit / fitPlanePCA / computeCentroid / computeCovariance /
 //                      Eigen solve / computePlaneDistances / mask compare / split + recursion
 //                      (recursive_patchwork.cpp:77-308). One OWNER wave per (frame, patch) runs the passes; the dependent
 //                      adds of its sequential sums run on the owner itself (patch_fit1_kernel<1>), on the owner while a
@@ -116,22 +116,25 @@ __device__ __forceinline__ uint32_t frame_of_tile(const uint32_t* __restrict__ t
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: classify + TILE-LOCAL stable sort. One pass over the input: every tile of 2048 points is
-// read once (12 B/pt), classified, ranked (stable: wave-contiguous sub-tiles, ballot/mbcnt ranks, exclusive
-// prefix over the 4 waves and over the classes) and written back grouped by patch INSIDE the tile's own
-// 2048-slot region (16 B/pt), together with two small directories per tile: the run length of every class
-// (hist, turned into patch-relative destination offsets by K2) and the run start inside the tile (tdir).
-// The per-patch contiguous arrays are then assembled by patch_fit itself (its gather prologue), where
-// bandwidth is idle, so the binning pass touches HBM with 12 + 16 (+1 label) bytes per point.
+// K1: the binning pass, two launches of one kernel around K2 (a counting sort by patch, stable):
+//   PASS 0 (bin_count)    every tile of 2048 points is read (12 B/pt) and classified; the tile's count of every class goes
+//                         to hist[tile][class] and, with integer atomics, into the frame's class totals (ftot)
+//   K2 (scan_offsets)     turns the counts into destinations: hist[tile][class] = first slot, relative to the frame, of
+//                         this tile's points of that class in the patch-sorted arrays
+//   PASS 1 (bin_scatter)  the tile is read and classified again (the same deterministic arithmetic), its points are ranked
+//                         inside the tile (stable: wave-contiguous sub-tiles, ballot/mbcnt ranks, exclusive prefix over the
+//                         4 waves) and written STRAIGHT to their final slots sx / sy / sz / sidx (16 B/pt): patch by patch,
+//                         input order kept inside a patch (recursive_patchwork.cpp:372-378: patch_points in zone order)
+// 40 bytes per point through HBM for "radial-sector scatter + per-bin prefix-sum compaction". (Rounds 1-2 wrote tile-sorted
+// 16-byte records in ONE pass and let patch_fit gather each patch's runs: 28 + 32 = 60 bytes per point, the gather's 32 at
+// patch_fit's low rate. A one-pass scatter would need every tile of a frame resident at once to wait for the frame's class
+// totals -- a spin on other workgroups that concurrent launches on other streams can starve; not built.)
 // ------------------------------------------------------------------------------------------
-template <bool STRIDED, bool FUSED>
-__global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
+template <bool STRIDED, bool FUSED, int PASS>
+__device__ __forceinline__ void bin_tile_body(const DevParams& p, uint32_t* lds_u32)
 {
-    extern __shared__ uint32_t lds_u32[];
-    uint32_t* wcnt = lds_u32;                                     // [4][PB] per-wave running counts, then wave offsets
-    uint32_t* tstart = lds_u32 + 4 * p.PB;                        // [PB] class totals, then run starts inside the tile
-    float* bnd = reinterpret_cast<float*>(lds_u32 + 5 * p.PB);    // [S+1] sector bounds
-    __shared__ uint32_t red[8];
+    uint32_t* wcnt = lds_u32;                                     // [4][PB] per-wave running counts, then (PASS 1) the wave's first slot
+    float* bnd = reinterpret_cast<float*>(lds_u32 + 4 * p.PB);    // [S+1] sector bounds
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int j = tid; j < 4 * p.PB; j += kTileThreads) wcnt[j] = 0;
     for (int j = tid; j <= p.S; j += kTileThreads) bnd[j] = p.bounds[j];
@@ -174,12 +177,12 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
         if (FUSED && ego) c = p.P + 3;                     // removed by the fusion step: in no cloud at all
         cls[r] = valid ? c : p.P;
         loff[r] = 0;
-        if (valid) {
+        if (PASS == 1 && valid) {
             // points of a patch get their label (0 or 1) from patch_fit; only the special classes are labelled here
             if (c >= p.P) p.labels[fo + i] = (uint8_t)(c == p.P ? RPW_LABEL_NONGROUND : (c == p.P + 1 ? RPW_LABEL_OUTSIDE : (c == p.P + 2 ? RPW_LABEL_DROPPED : RPW_LABEL_EGO)));
             if (p.residual) p.residual[fo + i] = -1.0f;
         }
-        // stable rank inside the wave's sub-tile: one step per distinct class of the row
+        // count (PASS 0) / stable rank (PASS 1) inside the wave's sub-tile: one step per distinct class of the row
         const unsigned long long vmask = ballot64(valid);
         unsigned long long rem = vmask;
         for (int steps = 0; rem && steps < kRankSteps; ++steps) {
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
             const bool same = cls[r] == c0;                                // (an out-of-range lane may match: its offset is never used)
             const unsigned long long m = ballot64(same) & vmask;
             const uint32_t old = mycnt[c0];
-            loff[r] = same ? old + (uint32_t)mbcnt64(m) : loff[r];
+            if (PASS == 1) loff[r] = same ? old + (uint32_t)mbcnt64(m) : loff[r];
             mycnt[c0] = old + (uint32_t)__popcll(m);                       // every lane stores the same value: no exec juggling
             rem &= ~m;
         }
@@ -207,51 +210,60 @@ __global__ __launch_bounds__(kTileThreads) void bin_tile_kernel(DevParams p)
             const uint32_t rank = (uint32_t)mbcnt64(mm);
             uint32_t run = 0;
             if (todo && rank == 0) { run = mycnt[cls[r]]; mycnt[cls[r]] = run + (uint32_t)__popcll(mm); }
-            run = (uint32_t)__shfl((int)run, __ffsll((long long)mm) - 1);
-            loff[r] = todo ? run + rank : loff[r];
+            if (PASS == 1) {
+                run = (uint32_t)__shfl((int)run, __ffsll((long long)mm) - 1);
+                loff[r] = todo ? run + rank : loff[r];
+            }
         }
     }
     __syncthreads();
-    for (int c = tid; c < p.PB; c += kTileThreads) {              // exclusive prefix over the 4 waves, class total
-        uint32_t s = 0;
+    uint32_t* hist_row = p.hist + (size_t)tile * p.PB;
+    if (PASS == 0) {
+        // the tile's count of every class (patch classes and the four special ones), and the frame's totals
+        uint32_t* ftot = p.ftot + (size_t)f * p.PB;                 // integer adds: order-free
+        for (int c = tid; c < p.P + 4; c += kTileThreads) {
+            const uint32_t v = wcnt[c] + wcnt[p.PB + c] + wcnt[2 * p.PB + c] + wcnt[3 * p.PB + c];
+            hist_row[c] = v;
+            if (v) atomicAdd(&ftot[c], v);                          // a tile of scan-ordered points touches a few classes only
+        }
+        return;
+    }
+    // PASS 1: first slot of every (wave, class) of this tile = the tile's destination of that class (K2) + the waves before
+    for (int c = tid; c < p.P; c += kTileThreads) {
+        uint32_t s = hist_row[c];
 #pragma unroll
         for (int w = 0; w < 4; ++w) { const uint32_t t = wcnt[w * p.PB + c]; wcnt[w * p.PB + c] = s; s += t; }
-        tstart[c] = s;
     }
     __syncthreads();
-    uint32_t* hist_out = p.hist + (size_t)tile * p.PB;
-    uint32_t* tdir_out = p.tdir + (size_t)tile * p.PB;
-    uint32_t* ftot = p.ftot + (size_t)f * p.PB;                     // class totals of the frame (integer adds: order-free)
-    uint32_t running = 0;
-    for (int c0 = 0; c0 < p.P; c0 += kTileThreads) {              // exclusive prefix over the patch classes
-        const int c = c0 + tid;
-        const uint32_t v = c < p.P ? tstart[c] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_excl_scan(v, red, total);
-        if (c < p.P) {
-            const uint32_t start = running + ex;
-            hist_out[c] = v; tdir_out[c] = start;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) wcnt[w * p.PB + c] += start;  // run start + the wave's offset inside the run
-            if (v) atomicAdd(&ftot[c], v);                           // a tile of scan-ordered points touches a few classes only
-        }
-        running += total;
-    }
-    if (tid < 4) {                                                  // special classes: totals only
-        const uint32_t v = tstart[p.P + tid];
-        hist_out[p.P + tid] = v;
-        if (v) atomicAdd(&ftot[p.P + tid], v);
-    }
-    __syncthreads();
-    char* tile_bytes = reinterpret_cast<char*>(p.tp + fo + t_local * kTilePoints);
+    char* fx = reinterpret_cast<char*>(p.sx + fo);                  // uniform frame bases + 32-bit byte offsets
+    char* fy = reinterpret_cast<char*>(p.sy + fo);
+    char* fz = reinterpret_cast<char*>(p.sz + fo);
+    char* fi = reinterpret_cast<char*>(p.sidx + fo);
 #pragma unroll
     for (int r = 0; r < kTileItems; ++r) {
         const uint32_t i = wbase + r * kWave + lane;
         if (i < nf && cls[r] < p.P) {
-            const uint32_t slot = mycnt[cls[r]] + loff[r];                            // inside the tile's region
-            *reinterpret_cast<float4*>(tile_bytes + slot * 16u) = make_float4(q[r].x, q[r].y, q[r].z, __uint_as_float(i));   // one 16-byte store
+            const uint32_t b = (mycnt[cls[r]] + loff[r]) * 4u;       // slot inside the frame's region, in bytes
+            *reinterpret_cast<float*>(fx + b) = q[r].x;
+            *reinterpret_cast<float*>(fy + b) = q[r].y;
+            *reinterpret_cast<float*>(fz + b) = q[r].z;
+            *reinterpret_cast<uint32_t*>(fi + b) = i;
         }
     }
+}
+
+// (two kernels with names of their own, so that profiles tell the passes apart)
+template <bool STRIDED, bool FUSED>
+__global__ __launch_bounds__(kTileThreads) void bin_count_kernel(DevParams p)
+{
+    extern __shared__ uint32_t lds_u32[];
+    bin_tile_body<STRIDED, FUSED, 0>(p, lds_u32);
+}
+template <bool STRIDED, bool FUSED>
+__global__ __launch_bounds__(kTileThreads) void bin_scatter_kernel(DevParams p)
+{
+    extern __shared__ uint32_t lds_u32[];
+    bin_tile_body<STRIDED, FUSED, 1>(p, lds_u32);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -284,16 +296,16 @@ __device__ __forceinline__ uint32_t scan_block_excl_scan(uint32_t v, uint32_t* r
 
 __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
 {
-    // One block per frame. The class totals of the frame are there already (bin_tile added them up), so the
-    // usual frame needs one scan over the classes and nothing else. Only a frame of more than kGatherTiles
-    // tiles has its run lengths turned into offsets here (patch_fit cannot hold its run directory in LDS then):
-    // class c is walked by `parts` threads, each over a contiguous range of tiles.
+    // One block per frame. The class totals of the frame are there already (bin_tile's counting pass added them up): one scan
+    // over the classes gives the patch begins, the patch descriptors and the size-bucket lists. Then the per-tile counts
+    // hist[tile][class] become the destinations of bin_tile's scatter pass -- patch begin + the points of that class in the
+    // tiles before, in tile (= input) order: class c is walked by `parts` threads, each over a contiguous range of tiles.
     extern __shared__ uint32_t lds_u32[];
     const int C = p.P + 4;
     int parts = kScanThreads / C; if (parts > 16) parts = 16; if (parts < 1) parts = 1;
     uint32_t* tot = lds_u32;                  // [PB] per-class totals, then patch_begin
     uint32_t* lrank = lds_u32 + p.PB;         // [PB] per patch: size bucket << 16 | rank inside the block's share of it
-    uint32_t* part = lds_u32 + 2 * p.PB;      // [parts][PB] partial totals, then exclusive prefix over parts (big frames)
+    uint32_t* part = lds_u32 + 2 * p.PB;      // [parts][PB] partial totals, then exclusive prefix over parts
     __shared__ uint32_t red[kScanThreads / 64];
     __shared__ uint32_t bcount[kBuckets];
     const int tid = threadIdx.x;
@@ -304,23 +316,20 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
     const uint32_t nf = p.frame_off[f + 1] - fo;
     uint32_t* base = p.hist + (size_t)t0 * p.PB;
     const uint32_t per = (nt + parts - 1) / parts;
-    const bool big = nt > (uint32_t)kGatherTiles;
 
     for (int c = tid; c < C; c += kScanThreads) tot[c] = p.ftot[(size_t)f * p.PB + c];
-    if (big) {
-        for (int w = tid; w < C * parts; w += kScanThreads) {
-            const int c = w % C, pt = w / C;
-            const uint32_t ta = pt * per, tb = ta + per < nt ? ta + per : nt;
-            uint32_t acc = 0;
+    for (int w = tid; w < p.P * parts; w += kScanThreads) {
+        const int c = w % p.P, pt = w / p.P;
+        const uint32_t ta = pt * per, tb = ta + per < nt ? ta + per : nt;
+        uint32_t acc = 0;
 #pragma unroll 8
-            for (uint32_t t = ta; t < tb; ++t) acc += base[(size_t)t * p.PB + c];
-            part[pt * p.PB + c] = acc;
-        }
-        __syncthreads();
-        for (int c = tid; c < C; c += kScanThreads) {
-            uint32_t s = 0;
-            for (int pt = 0; pt < parts; ++pt) { const uint32_t v = part[pt * p.PB + c]; part[pt * p.PB + c] = s; s += v; }
-        }
+        for (uint32_t t = ta; t < tb; ++t) acc += base[(size_t)t * p.PB + c];
+        part[pt * p.PB + c] = acc;
+    }
+    __syncthreads();
+    for (int c = tid; c < p.P; c += kScanThreads) {
+        uint32_t s = 0;
+        for (int pt = 0; pt < parts; ++pt) { const uint32_t v = part[pt * p.PB + c]; part[pt * p.PB + c] = s; s += v; }
     }
     __syncthreads();
     // zone < 3: the reference returns {{}, cleaned} before looking at any patch (recursive_patchwork.cpp:339-341)
@@ -359,8 +368,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_offsets_kernel(DevParams p)
             p.bucket_list[(size_t)b * p.list_stride + bcount[b] + (lr & 0xffffu)] = f * (uint32_t)p.P + (uint32_t)c;
         }
     }
-    // big frames only: running offsets per class over the tiles, in tile (= input) order
-    if (big) for (int w = tid; w < p.P * parts; w += kScanThreads) {
+    // counts -> destinations: running offsets per class over the tiles, in tile (= input) order
+    for (int w = tid; w < p.P * parts; w += kScanThreads) {
         const int c = w % p.P, pt = w / p.P;
         const uint32_t ta = pt * per, tb = ta + per < nt ? ta + per : nt;
         uint32_t off = tot[c] + part[pt * p.PB + c];
@@ -439,20 +448,14 @@ __device__ __forceinline__ void emit_node(const DevParams& p, int tid, int frame
 //     no barrier, flag or second wave is involved.
 // Per refit iteration: covariance sweep over the inliers (6 rows) -> eigenvector -> mask pass over the node ->
 // centroid sweep over the new inliers (3 rows), or, when the mask did not change, the residual sweep (1 row).
-// Everything else (gather, early-outs, order statistics, partition, labels) is the same arithmetic as above,
+// Everything else (early-outs, order statistics, partition, labels) is the same arithmetic as above,
 // executed by 64 lanes. Sums are accumulated in exactly the reference's order (recursive_patchwork.cpp:98-104,
 // 383-387, 241-248; point_cloud_processor.cpp:63-67, 78-83).
 // ==========================================================================================
 constexpr int kW1Ring = 3;           // ring slots: slot u lives in ring slot u % 3, a compile-time constant inside the loop unrolled by three
 
 struct Fit1Shared {
-    union {                            // the gather prologue is over before the first chain sweep
-        __attribute__((aligned(16))) float ring[2 * kGatherTiles];     // sweeps: kW1Ring * kSlotFloats floats; fused pass: kFSlots * kFSlotFloats
-        struct {
-            uint32_t toff[kGatherTiles];
-            uint32_t tsrc[kGatherTiles];
-        } dir;
-    };
+    __attribute__((aligned(16))) float ring[kRingFloats];              // sweeps: kW1Ring * kSlotFloats floats; fused pass: kFSlots * kFSlotFloats
     uint32_t hist[256];
     uint32_t stk[3 * kStackDepth];
     // two-wave form only: the command the chain wave hands the helper wave, and the fused pass's hand-off words
@@ -460,7 +463,7 @@ struct Fit1Shared {
     uint32_t fcur[2];                  // inliers written up to the end of round r, in fcur[r & 1]
     uint32_t fflags[2];                // changed / differs-from-the-mask-before, of the whole pass
 };
-static_assert(kW1Ring * kSlotFloats <= 2 * kGatherTiles, "the sweep ring must fit the union");
+static_assert(kW1Ring * kSlotFloats <= kRingFloats, "the sweep ring must fit");
 
 struct W1 {
     const float *sx, *sy, *sz;         // patch-sorted SoA
@@ -702,7 +705,7 @@ struct FusedChain {
         }
     }
 };
-static_assert(kFDump + 2 * kLdw + kWave <= 2 * kGatherTiles, "the fused ring and its dump rows must fit the union");
+static_assert(kFDump + 2 * kLdw + kWave <= kRingFloats, "the fused ring and its dump rows must fit");
 
 template <int MODE, int IW, class CH>
 __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskPrm& prm, lds_f32* ring, int lane, CH& ch)
@@ -1362,83 +1365,6 @@ __device__ __attribute__((noinline)) N3 w1_normal(float a00, float a10, float a1
     return r;
 }
 
-// Gather prologue (see patch_fit_kernel): assembles the patch's contiguous slots from its runs in the tile-sorted
-// records and returns the bounding box of the whole patch.
-struct Box6 { float v[6]; };
-struct GatherArgs {
-    const uint32_t *goff, *gdir;       // this patch's column of the run-length / run-start directories, first tile of the frame
-    const float4* tp;
-    float *sx, *sy, *sz; uint32_t* sidx;
-    uint32_t nt, PB, fo, begin, n;
-};
-__device__ __attribute__((noinline)) Box6 w1_gather(GatherArgs g, lds_word* toff, lds_word* tsrc)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t nt = g.nt;
-    const bool in_lds = nt <= (uint32_t)kGatherTiles;
-    if (in_lds) {
-        const uint32_t per = (nt + kFit1Threads - 1) / kFit1Threads;
-        const uint32_t ta = (uint32_t)lane * per, tb = ta + per < nt ? ta + per : nt;
-        uint32_t sum = 0;
-        for (uint32_t t = ta; t < tb; ++t) {
-            const uint32_t len = g.goff[(size_t)t * g.PB];
-            toff[t] = len; sum += len;
-            tsrc[t] = t * kTilePoints + g.gdir[(size_t)t * g.PB];
-        }
-        const uint32_t incl = wave_incl_scan(sum);
-        uint32_t run = incl - sum;
-        for (uint32_t t = ta; t < tb; ++t) { const uint32_t len = toff[t]; toff[t] = run; run += len; }
-    }
-    wave_sync();
-    const uint32_t rel0 = in_lds ? 0u : g.begin - g.fo;
-    uint32_t top = 1; while (top * 2u < nt) top *= 2u;
-    constexpr int kGatherWide = 8;
-    float xmn = 3.402823466e+38f, xmx = -3.402823466e+38f, ymn = xmn, ymx = xmx, zmn = xmn, zmx = xmx;
-    for (uint32_t j0 = lane; j0 < g.n; j0 += kGatherWide * kFit1Threads) {
-        uint32_t src[kGatherWide], d[kGatherWide], lo[kGatherWide]; float4 v4[kGatherWide];
-#pragma unroll
-        for (int u = 0; u < kGatherWide; ++u) { const uint32_t j = j0 + u * kFit1Threads; d[u] = rel0 + (j < g.n ? j : g.n - 1u); lo[u] = 0; }
-        if (in_lds) {
-            for (uint32_t step = top; step > 0; step >>= 1) {
-                uint32_t v[kGatherWide];
-#pragma unroll
-                for (int u = 0; u < kGatherWide; ++u) { const uint32_t mid = lo[u] + step; v[u] = toff[mid < nt ? mid : nt - 1u]; }
-#pragma unroll
-                for (int u = 0; u < kGatherWide; ++u) { const uint32_t mid = lo[u] + step; lo[u] = ((mid < nt) & (v[u] <= d[u])) ? mid : lo[u]; }
-            }
-#pragma unroll
-            for (int u = 0; u < kGatherWide; ++u) { const uint32_t o = toff[lo[u]], sb = tsrc[lo[u]]; src[u] = g.fo + sb + (d[u] - o); }
-        } else {
-            for (uint32_t step = top; step > 0; step >>= 1) {
-#pragma unroll
-                for (int u = 0; u < kGatherWide; ++u) {
-                    const uint32_t mid = lo[u] + step, mc = mid < nt ? mid : nt - 1u;
-                    lo[u] = (mid < nt && g.goff[(size_t)mc * g.PB] <= d[u]) ? mid : lo[u];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < kGatherWide; ++u)
-                src[u] = g.fo + lo[u] * kTilePoints + g.gdir[(size_t)lo[u] * g.PB] + (d[u] - g.goff[(size_t)lo[u] * g.PB]);
-        }
-#pragma unroll
-        for (int u = 0; u < kGatherWide; ++u) v4[u] = g.tp[src[u]];
-#pragma unroll
-        for (int u = 0; u < kGatherWide; ++u) {
-            const uint32_t j = j0 + u * kFit1Threads;
-            if (j < g.n) {
-                const uint32_t dst = g.begin + j;
-                g.sx[dst] = v4[u].x; g.sy[dst] = v4[u].y; g.sz[dst] = v4[u].z; g.sidx[dst] = __float_as_uint(v4[u].w);
-            }
-            xmn = fminf(xmn, v4[u].x); xmx = fmaxf(xmx, v4[u].x); ymn = fminf(ymn, v4[u].y); ymx = fmaxf(ymx, v4[u].y);
-            zmn = fminf(zmn, v4[u].z); zmx = fmaxf(zmx, v4[u].z);
-        }
-    }
-    Box6 b;
-    b.v[0] = wave_min(xmn); b.v[1] = wave_max(xmx); b.v[2] = wave_min(ymn); b.v[3] = wave_max(ymx);
-    b.v[4] = wave_min(zmn); b.v[5] = wave_max(zmx);
-    return b;
-}
-
 // ==========================================================================================
 // CHAIN-SERVER FORM (the default). In the forms above every dependent add is a whole vector instruction that keeps 3 or 6
 // of 64 lanes busy, and a saturated SIMD issues one vector instruction per ~4.6 cycles whatever its lane mask
@@ -1460,7 +1386,7 @@ __device__ __attribute__((noinline)) Box6 w1_gather(GatherArgs g, lds_word* toff
 constexpr int kSrvFeeders = 7;
 constexpr int kSrvSweepSlots = 4;        // ring slots of a sweep (6 rows of 64 each); the fused pass uses kFSlots slots of 3 rows
 constexpr uint32_t kSrvSpinLimit = 1u << 25;      // polls (>= ~200 cycles each: seconds) before a wait gives up
-static_assert(kSrvSweepSlots * kSlotFloats <= 2 * kGatherTiles, "the server form's sweep ring must fit the union");
+static_assert(kSrvSweepSlots * kSlotFloats <= kRingFloats, "the server form's sweep ring must fit");
 static_assert(6 * kSrvFeeders <= kWave, "six server lanes per feeder");
 
 struct SrvShared {
@@ -1557,7 +1483,7 @@ __device__ __attribute__((noinline)) void srv_loop(SrvShared* sv, Fit1Shared* sh
     for (;;) {
         // ---- nothing in flight: wait for a slot (or for the feeders to leave) ----
         // (No limit on the server's own polls: every feeder's waits are bounded, so every feeder leaves, and the server leaves
-        // behind the last of them. A limit here could only fire on feeders that are legitimately busy elsewhere -- the gather
+        // behind the last of them. A limit here could only fire on feeders that are legitimately busy elsewhere -- the bounding box
         // or the radix select of a very large patch.)
         for (;;) {
             const v4u st = *fw;
@@ -1779,23 +1705,6 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
     cx.base = pd.begin; cx.lane = lane; cx.addends = 0ull;
     const rpw_config& cfg = p.cfg;
     uint32_t* stk = sh.stk;
-    float rootbox[6];
-
-    // ---- gather: assemble the patch's contiguous slots from its runs in the tile-sorted arrays ----------------
-    {
-        const uint32_t t0 = p.tile_base[frame];
-        GatherArgs g;
-        g.goff = p.hist + (size_t)t0 * p.PB + patch; g.gdir = p.tdir + (size_t)t0 * p.PB + patch; g.tp = p.tp;
-        g.sx = p.sx; g.sy = p.sy; g.sz = p.sz; g.sidx = p.sidx;
-        g.nt = p.tile_base[frame + 1] - t0; g.PB = (uint32_t)p.PB; g.fo = fo; g.begin = pd.begin; g.n = pd.n;
-        Box6 b;
-        W1_PH(0, pd.n, b = w1_gather(g, (lds_word*)sh.dir.toff, (lds_word*)sh.dir.tsrc))
-#pragma unroll
-        for (int k = 0; k < 6; ++k) rootbox[k] = b.v[k];
-        wave_sync();                               // the directory's LDS becomes the ring; the wave's own stores are ordered
-    }
-
-    if (p.gather_only) { W_LEAVE() return; }            // diagnostic: the binning pass ends here (per-patch compaction done)
 
     // zone < 3: the reference returns {{}, cleaned} before looking at any patch (recursive_patchwork.cpp:339-341)
     if (p.stats[frame].n_zone < 3u) {
@@ -1845,9 +1754,8 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
         int leaf_kind = -1;
         if (n < 3 || depth > cfg.max_split_depth) leaf_kind = RPW_NODE_REJECT;
         if (leaf_kind < 0) {
-            float xmn = rootbox[0], xmx = rootbox[1], ymn = rootbox[2], ymx = rootbox[3], zmn = rootbox[4], zmx = rootbox[5];
-            if (depth > 0) {
-                xmn = 3.402823466e+38f; xmx = -3.402823466e+38f; ymn = xmn; ymx = xmx; zmn = xmn; zmx = xmx;
+            float xmn = 3.402823466e+38f, xmx = -3.402823466e+38f, ymn = xmn, ymx = xmx, zmn = xmn, zmx = xmx;
+            {
                 for (uint32_t i0 = lane; i0 < n; i0 += 4 * kFit1Threads) {
                     float x[4], y[4], z[4];
 #pragma unroll
@@ -2258,19 +2166,20 @@ __global__ __launch_bounds__(256) void frame_copy_out_kernel(const uint8_t* __re
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-void launch_bin(const DevParams& p, hipStream_t s)
-{
-    if (p.tile_count == 0) return;
-    const size_t lds = (size_t)(5 * p.PB + p.S + 1) * 4;
-    const dim3 g(p.tile_count), b(kTileThreads);
-    if (p.sensors.n > 0) {
-        if (p.in_stride == 12u) hipLaunchKernelGGL((bin_tile_kernel<false, true>), g, b, lds, s, p);
-        else                    hipLaunchKernelGGL((bin_tile_kernel<true, true>), g, b, lds, s, p);
-    } else {
-        if (p.in_stride == 12u) hipLaunchKernelGGL((bin_tile_kernel<false, false>), g, b, lds, s, p);
-        else                    hipLaunchKernelGGL((bin_tile_kernel<true, false>), g, b, lds, s, p);
+#define RPW_LAUNCH_BIN(KERNEL)                                                                              \
+    if (p.tile_count == 0) return;                                                                         \
+    const size_t lds = (size_t)(4 * p.PB + p.S + 1) * 4;                                                   \
+    const dim3 g(p.tile_count), b(kTileThreads);                                                           \
+    if (p.sensors.n > 0) {                                                                                 \
+        if (p.in_stride == 12u) hipLaunchKernelGGL((KERNEL<false, true>), g, b, lds, s, p);                \
+        else                    hipLaunchKernelGGL((KERNEL<true, true>), g, b, lds, s, p);                 \
+    } else {                                                                                               \
+        if (p.in_stride == 12u) hipLaunchKernelGGL((KERNEL<false, false>), g, b, lds, s, p);               \
+        else                    hipLaunchKernelGGL((KERNEL<true, false>), g, b, lds, s, p);                \
     }
-}
+void launch_bin_count(const DevParams& p, hipStream_t s) { RPW_LAUNCH_BIN(bin_count_kernel) }
+void launch_bin_scatter(const DevParams& p, hipStream_t s) { RPW_LAUNCH_BIN(bin_scatter_kernel) }
+#undef RPW_LAUNCH_BIN
 void launch_scan(const DevParams& p, hipStream_t s)
 {
     if (p.frame_count == 0) return;

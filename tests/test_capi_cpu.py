@@ -31,7 +31,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", rpw_amd.LIB_PATH], text=True)
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
     assert set(syms) <= exported
-    assert lib.rpw_abi_version() == 2
+    assert lib.rpw_abi_version() == 3
 
 
 def test_no_oracle_linked_into_product():

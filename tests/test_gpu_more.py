@@ -62,9 +62,9 @@ def test_full_size_parity_with_trace(engine_factory, name, kw):
         assert st["max_depth"] == kw["max_split_depth"] and st["n_splits"] > 100      # the recursion did reach the configured depth
 
 
-def test_result_record_on_device_and_gather_only_diagnostic(engine_factory):
+def test_result_record_on_device(engine_factory):
     """rpw_result_record_device: the per-frame record the multi-GPU gather sends, written behind the batch on ANOTHER
-    stream (event dependency), equals the batch stats. The gather-only diagnostic launch leaves the handle usable."""
+    stream (event dependency), equals the batch stats."""
     import torch
     # (the last frame reaches beyond filtering_radius: its outside points belong to the reference's non_ground_points)
     frames = [W.c2_hdl64(1), W.c1_test_cloud(2), W.c2_hdl64(2)[::2], W.c1_test_cloud(4) * np.array([4, 4, 1], np.float32)]
@@ -91,10 +91,6 @@ def test_result_record_on_device_and_gather_only_diagnostic(engine_factory):
         if f == len(frames) - 1:
             assert ref.stats["n_clean"] > ref.stats["n_zone"]        # the frame does have points beyond the radius
         assert int(st["n_ground"][f]) == ref.stats["n_ground"]
-    eng.set_debug_gather_only(True)
-    eng.segment_batch_device(d_xyz.data_ptr(), off, d_lab.data_ptr(), None, s_batch.cuda_stream)
-    eng.set_debug_gather_only(False)
-    eng.segment_batch_device(d_xyz.data_ptr(), off, d_lab.data_ptr(), None, s_batch.cuda_stream)
     torch.cuda.synchronize()
     lab = d_lab.cpu().numpy()
     for f, xyz in enumerate(frames):

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Re-collects everything under profiles/ that DESIGN.md and bench.py quote, for the current build (round tag below).
 # Run on the GPU box from the repo root (about 6 minutes):  bash tools/refresh_profiles.sh gpurun_out/prof
-# Afterwards copy the r02_* files it lists from gpurun_out/prof/export/ into profiles/ and commit them.
+# Afterwards copy the r03_* files it lists from gpurun_out/prof/export/ into profiles/ and commit them.
 set -e
-R=r02
+R=r03
 OUT=${1:-gpurun_out/prof}; mkdir -p "$OUT" "$OUT/export"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 # 1. HBM traffic (PMC) first: bench.py reads the bench-batch figure from profiles/
