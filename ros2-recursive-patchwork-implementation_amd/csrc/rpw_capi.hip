@@ -343,6 +343,7 @@ void fill_params(rpw_handle* h, Workspace& w, DevParams& p, const void* d_xyz, u
     p.bucket_count = w.d_ctrl; p.bucket_list = w.d_bucket_list; p.list_stride = w.max_frames * (uint32_t)h->P;
     p.sx = w.d_sx; p.sy = w.d_sy; p.sz = w.d_sz; p.sidx = w.d_sidx; p.ax = w.d_ax; p.ay = w.d_ay; p.az = w.d_az;
     p.mask = w.d_mask; p.stats = w.d_stats;
+    { static const int remap = [] { const char* e = getenv("RPW_BIN_REMAP"); return e ? atoi(e) : 1; }(); p.bin_remap = remap; }
     // the trace buffer belongs to the handle: only its own workspace writes it
     const bool tracing = (&w == &h->ws) && h->trace && h->d_nodes;
     p.trace = tracing ? 1 : 0; p.nodes = tracing ? h->d_nodes : nullptr; p.node_count = w.d_ctrl + kBuckets; p.work = w.d_ctrl + kBuckets + 1; p.nodes_cap = tracing ? h->nodes_cap : 0;

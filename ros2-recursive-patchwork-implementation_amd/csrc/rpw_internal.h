@@ -76,6 +76,7 @@ struct DevParams {
     uint32_t* work;               // [0] work counter of patch_fit's chain-server form, [1] its error flag (zeroed with the bucket counts)
     uint32_t  nodes_cap;
     int       trace;
+    int       bin_remap;          // bin_tile: XCD-contiguous tile order
 };
 
 void launch_bin_count(const DevParams& p, hipStream_t s);

@@ -140,7 +140,14 @@ __device__ __forceinline__ void bin_tile_body(const DevParams& p, uint32_t* lds_
     for (int j = tid; j <= p.S; j += kTileThreads) bnd[j] = p.bounds[j];
     __syncthreads();
 
-    const uint32_t tile = blockIdx.x + p.tile_first;
+    // Workgroups b and b + 8 share an XCD (observed round-robin placement; speed only, never correctness): give every XCD
+    // a contiguous range of tiles, so that the adjacent runs consecutive tiles write meet in ONE L2 and leave it as whole lines.
+    uint32_t bid = blockIdx.x;
+    if (p.bin_remap) {
+        const uint32_t q = p.tile_count / 8u, r = p.tile_count % 8u, x = bid % 8u;
+        bid = (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + bid / 8u;
+    }
+    const uint32_t tile = bid + p.tile_first;
     const uint32_t f = frame_of_tile(p.tile_base, p.n_frames, tile);
     const uint32_t fo = p.frame_off[f];
     const uint32_t nf = p.frame_off[f + 1] - fo;
@@ -190,9 +197,13 @@ __device__ __forceinline__ void bin_tile_body(const DevParams& p, uint32_t* lds_
             const int c0 = __builtin_amdgcn_readlane(cls[r], first);      // `first` is wave-uniform: no LDS round trip
             const bool same = cls[r] == c0;                                // (an out-of-range lane may match: its offset is never used)
             const unsigned long long m = ballot64(same) & vmask;
-            const uint32_t old = mycnt[c0];
-            if (PASS == 1) loff[r] = same ? old + (uint32_t)mbcnt64(m) : loff[r];
-            mycnt[c0] = old + (uint32_t)__popcll(m);                       // every lane stores the same value: no exec juggling
+            if (PASS == 1) {
+                const uint32_t old = mycnt[c0];
+                loff[r] = same ? old + (uint32_t)mbcnt64(m) : loff[r];
+                mycnt[c0] = old + (uint32_t)__popcll(m);                   // every lane stores the same value: no exec juggling
+            } else if (lane == 0) {
+                atomicAdd(&mycnt[c0], (uint32_t)__popcll(m));              // counting only: an LDS add that returns nothing (no round trip)
+            }
             rem &= ~m;
         }
         if (rem) {
@@ -209,7 +220,8 @@ __device__ __forceinline__ void bin_tile_body(const DevParams& p, uint32_t* lds_
             }
             const uint32_t rank = (uint32_t)mbcnt64(mm);
             uint32_t run = 0;
-            if (todo && rank == 0) { run = mycnt[cls[r]]; mycnt[cls[r]] = run + (uint32_t)__popcll(mm); }
+            if (PASS == 0) { if (todo && rank == 0) atomicAdd(&mycnt[cls[r]], (uint32_t)__popcll(mm)); }
+            else if (todo && rank == 0) { run = mycnt[cls[r]]; mycnt[cls[r]] = run + (uint32_t)__popcll(mm); }
             if (PASS == 1) {
                 run = (uint32_t)__shfl((int)run, __ffsll((long long)mm) - 1);
                 loff[r] = todo ? run + rank : loff[r];
