@@ -4,9 +4,9 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path (classify+bin -> per-patch compaction -> recursive plane fit -> labels) over one
-batch of synthetic HDL-64-like frames that is already resident in HBM (BASELINE.json configs[1]/[2]: ~126 k points per
-frame, max_split_depth = 3). Frames are independent, so N GPUs run N such batches with no data-path collective ("weak"
+A "step" is one pass of the hot path (binning: count, scan, scatter into patch-sorted arrays -> recursive plane fit ->
+labels) over one batch of 2048 synthetic HDL-64-like frames that is already resident in HBM (BASELINE.json
+configs[1]/[2]: ~126 k points per frame, max_split_depth = 3). Frames are independent, so N GPUs run N such batches with no data-path collective ("weak"
 scaling); the only RCCL call is the gather of every batch's per-frame result record.
 
 `value` is that device-resident throughput. The same JSON line also carries what the DROP-IN path does, host memory in,
@@ -42,15 +42,15 @@ PROFILE_ROUND = "r03"
 
 
 WORKLOADS = {   # name: (generator, config, default frames per step, description) -- BASELINE.json `configs`
-    "c2": ("c2_hdl64", dict(max_split_depth=3), 512,
+    "c2": ("c2_hdl64", dict(max_split_depth=3), 2048,
            "c2_hdl64 (BASELINE.json configs[1]/[2]): seeded HDL-64-like ray-cast frames"),
-    "c1": ("c1_test_cloud", dict(), 2048, "c1_test_cloud (configs[0]): the reference test's 20 k-point clouds"),
-    "c4": ("c4_iac_fused", dict(max_split_depth=1000), 256,
+    "c1": ("c1_test_cloud", dict(), 8192, "c1_test_cloud (configs[0]): the reference test's 20 k-point clouds"),
+    "c4": ("c4_iac_fused", dict(max_split_depth=1000), 1024,
            "c4_iac_fused (configs[3]): 3 fused solid-state sensors, ~296 k points, deep recursion allowed"),
-    "c5": ("c5_dense", dict(max_split_depth=6), 64, "c5_dense (configs[4]): dense 1.09 M-point frames"),
-    "rough3": ("rough_terrain", dict(max_split_depth=3, th_dist=0.0005), 256,
+    "c5": ("c5_dense", dict(max_split_depth=6), 256, "c5_dense (configs[4]): dense 1.09 M-point frames"),
+    "rough3": ("rough_terrain", dict(max_split_depth=3, th_dist=0.0005), 1024,
                "rough_terrain: HDL-64-like scan + far-field clutter, th_dist 0.0005: fits split NATURALLY down to depth 3"),
-    "rough6": ("rough_terrain", dict(max_split_depth=6, th_dist=0.0005), 256,
+    "rough6": ("rough_terrain", dict(max_split_depth=6, th_dist=0.0005), 1024,
                "rough_terrain: the same scan, max_split_depth 6: natural splits down to depth 6"),
 }
 
@@ -278,12 +278,14 @@ def host_path_legs(rpw_amd, cfg_kw, frames, local_rank, seconds=0.8, slots=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=224, help="timed steps (default: a little over one second)")
+    ap.add_argument("--steps", type=int, default=56, help="timed steps (default: a little over one second)")
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 (default) is the configuration the metric is quoted on; the others are informational")
-    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (one batch); 0 = the workload's default (c2: 512)")
-    ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (HIP streams, one engine each)")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (one batch); 0 = the workload's default (c2: 2048)")
+    ap.add_argument("--streams", type=int, default=1, help="batches in flight per GPU (HIP streams, one engine each). Default 1: one launch of "
+                    "every kernel at a time, so a kernel's launch duration is its own (several batches in flight share the chip and "
+                    "stretch each other's launches; throughput is the same within 1-2 %)")
     ap.add_argument("--regions", type=int, default=0, help="timed regions of --steps steps each (value = the median region); "
                     "0 = as many as it takes to measure about one second, 1 = a single region")
     ap.add_argument("--max-iter", type=int, default=100,
@@ -337,9 +339,9 @@ def main():
     total_pts = int(offsets[-1])
     xyz_host = np.concatenate(frames, axis=0)
 
-    # One engine (C-ABI handle: own work buffers) + one HIP stream per batch in flight. Consecutive
-    # steps go to consecutive streams, so the serial tail of one batch (a few patches that need
-    # ~100 sequential refits) overlaps with the next batches instead of idling the chip.
+    # One engine (C-ABI handle: own work buffers) + one HIP stream per batch in flight. The default is ONE batch of 2048
+    # frames at a time: large enough that the serial tail of a launch (a few patches that need ~100 sequential refits,
+    # started first) is hidden inside it. With --streams k consecutive steps go to consecutive streams and overlap.
     n_streams = max(1, args.streams)
     engines = [rpw_amd.Engine(rpw_amd.PatchworkConfig(**cfg_kw), device=local_rank,
                               max_points=total_pts, max_frames=len(frames)) for _ in range(n_streams)]

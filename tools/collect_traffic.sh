@@ -13,7 +13,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   if [ -n "$PROBE" ]; then
     MAX_ITER=1 REPS=3 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$ROOT/$OUT/$C" -o t -- python3 "$ROOT/tools/binning_probe.py" > "$ROOT/$OUT/$C.probe.json" 2> "$ROOT/$OUT/$C.err"
   else
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$ROOT/$OUT/$C" -o t -- python3 "$ROOT/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-host-path "$@" > "$ROOT/$OUT/$C.bench.json" 2> "$ROOT/$OUT/$C.err"
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$ROOT/$OUT/$C" -o t -- python3 "$ROOT/bench.py" --steps 4 --warmup 1 --regions 1 --no-cpu-baseline --no-host-path "$@" > "$ROOT/$OUT/$C.bench.json" 2> "$ROOT/$OUT/$C.err"
   fi
 done
 python3 "$ROOT/tools/traffic_summary.py" "$ROOT/$OUT" > "$ROOT/$OUT/traffic.json"

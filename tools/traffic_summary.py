@@ -28,7 +28,7 @@ for kn, d in res.items():
 try:     # the batch the counters belong to (bench.py only quotes them for the same batch size)
     b = json.loads(open(os.path.join(root, "FETCH_SIZE.bench.json")).read().strip().splitlines()[-1])
     out["_meta"] = {"frames_per_launch": b["config"]["frames_per_gpu_per_step"], "points_per_frame": b["config"]["points_per_frame"],
-                    "command": "tools/collect_traffic.sh (bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-host-path)"}
+                    "command": "tools/collect_traffic.sh (bench.py --steps 4 --warmup 1 --regions 1 --no-cpu-baseline --no-host-path)"}
 except Exception:
     try:
         b = json.loads(open(os.path.join(root, "FETCH_SIZE.probe.json")).read().strip().splitlines()[-1])
