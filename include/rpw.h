@@ -251,6 +251,9 @@ rpw_status  rpw_debug_eig3(rpw_handle* h, const float* cov9, float* normal3, uin
  * covariance, residual, range, xy, variance), 16..18 fused / mask passes (seed, plane, older); + 32: the same loop in the
  * two-wave form (chain wave + helper wave). ms = device time of the launch. */
 rpw_status  rpw_debug_loop_bench(rpw_handle* h, int what, uint32_t n, uint32_t inlier_pct, int reps, uint32_t blocks, double* ms);
+/* The same, and the shader-clock ticks (s_memtime) node 0's owner wave spent in its `reps` passes: the chip's clock follows
+ * its recent load, so cycles -- not wall time -- compare the loops of a LONE patch. ticks may be NULL. */
+rpw_status  rpw_debug_loop_bench_ticks(rpw_handle* h, int what, uint32_t n, uint32_t inlier_pct, int reps, uint32_t blocks, double* ms, double* ticks);
 /* Host evaluation of the same atan2f restatement (no device needed). */
 void        rpw_debug_angles_host(const float* x, const float* y, float* angle, uint32_t n);
 

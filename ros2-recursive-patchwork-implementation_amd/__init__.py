@@ -163,6 +163,8 @@ def load_library():
     L.rpw_debug_eig3.restype = i32
     L.rpw_debug_loop_bench.argtypes = [vp, i32, u32, u32, i32, u32, C.POINTER(C.c_double)]
     L.rpw_debug_loop_bench.restype = i32
+    L.rpw_debug_loop_bench_ticks.argtypes = [vp, i32, u32, u32, i32, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rpw_debug_loop_bench_ticks.restype = i32
     L.rpw_debug_angles_host.argtypes = [vp, vp, vp, u32]
     L.rpw_debug_angles_host.restype = None
     _lib = L
@@ -175,7 +177,7 @@ EXPORTED_SYMBOLS = (
     "rpw_submit", "rpw_submit_pointcloud2", "rpw_poll", "rpw_wait", "rpw_set_sensors", "rpw_segment_fused",
     "rpw_segment_batch_device_fused", "rpw_segment_batch_device", "rpw_get_batch_stats", "rpw_set_trace",
     "rpw_get_nodes", "rpw_set_profiling", "rpw_get_kernel_ms", "rpw_debug_angles", "rpw_debug_eig3",
-    "rpw_debug_angles_host", "rpw_debug_loop_bench", "rpw_result_record_device",
+    "rpw_debug_angles_host", "rpw_debug_loop_bench", "rpw_debug_loop_bench_ticks", "rpw_result_record_device",
 )
 
 
@@ -363,6 +365,12 @@ class Engine:
         ms = C.c_double(0.0)
         self._check(self._L.rpw_debug_loop_bench(self._h, what, n, inlier_pct, reps, blocks, C.byref(ms)))
         return ms.value
+
+    def loop_bench_ticks(self, what: int, n: int, inlier_pct: int = 56, reps: int = 20, blocks: int = 1):
+        """-> (ms, shader-clock ticks node 0's owner wave spent in its passes): cycles compare lone-patch loops, whatever the chip's clock."""
+        ms, ticks = C.c_double(0.0), C.c_double(0.0)
+        self._check(self._L.rpw_debug_loop_bench_ticks(self._h, what, n, inlier_pct, reps, blocks, C.byref(ms), C.byref(ticks)))
+        return ms.value, ticks.value
 
     def debug_angles(self, x, y):
         x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)

@@ -906,10 +906,15 @@ rpw_status rpw_debug_eig3(rpw_handle* h, const float* cov9, float* normal3, uint
 
 rpw_status rpw_debug_loop_bench(rpw_handle* h, int what, uint32_t n, uint32_t inlier_pct, int reps, uint32_t blocks, double* ms)
 {
+    return rpw_debug_loop_bench_ticks(h, what, n, inlier_pct, reps, blocks, ms, nullptr);
+}
+
+rpw_status rpw_debug_loop_bench_ticks(rpw_handle* h, int what, uint32_t n, uint32_t inlier_pct, int reps, uint32_t blocks, double* ms, double* ticks)
+{
     if (!h || !ms || n == 0 || blocks == 0 || reps <= 0 || inlier_pct > 100) return RPW_ERR_INVALID;
     if ((uint64_t)n * blocks > (1ull << 28)) return fail(h, RPW_ERR_CAPACITY, "loop bench: n * blocks too large");
     const int base_what = what & 31;
-    if ((what & ~127) || (what & 96) == 96 || !((base_what >= 0 && base_what <= 6) || (base_what >= 16 && base_what <= 18)))
+    if ((what & ~127) || !((base_what >= 0 && base_what <= 7) || (base_what >= 16 && base_what <= 18)))
         return fail(h, RPW_ERR_INVALID, "loop bench: unknown loop %d", what);
     RPW_HIP(h, hipSetDevice(h->device));
     const size_t total = (size_t)n * blocks;
@@ -934,6 +939,8 @@ rpw_status rpw_debug_loop_bench(rpw_handle* h, int what, uint32_t n, uint32_t in
     if (e == hipSuccess) e = hipMalloc(&dil, total * 4);
     if (e == hipSuccess) e = hipMalloc(&dm, total);
     if (e == hipSuccess) e = hipMalloc(&dout, (size_t)blocks * 4);
+    unsigned long long* dticks = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&dticks, 8);
     for (uint32_t b = 0; e == hipSuccess && b < blocks; ++b) {
         e = hipMemcpy(dx + (size_t)b * n, x.data(), (size_t)n * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(dy + (size_t)b * n, y.data(), (size_t)n * 4, hipMemcpyHostToDevice);
@@ -947,13 +954,17 @@ rpw_status rpw_debug_loop_bench(rpw_handle* h, int what, uint32_t n, uint32_t in
     float t = 0.0f;
     if (e == hipSuccess) {
         const uint32_t cnt = base_what < 16 ? (base_what == kSweepRangeMode || base_what >= 4 ? n : count) : n;
-        launch_loop_bench(dx, dy, dz, dm, dil, n, cnt, what, 1, blocks, dout, nullptr);            // warm-up
+        launch_loop_bench(dx, dy, dz, dm, dil, n, cnt, what, 1, blocks, dout, dticks, nullptr);            // warm-up
         e = hipEventRecord(ea, nullptr);
-        launch_loop_bench(dx, dy, dz, dm, dil, n, cnt, what, reps, blocks, dout, nullptr);
+        launch_loop_bench(dx, dy, dz, dm, dil, n, cnt, what, reps, blocks, dout, dticks, nullptr);
         if (e == hipSuccess) e = hipEventRecord(eb, nullptr);
         if (e == hipSuccess) e = hipEventSynchronize(eb);
         if (e == hipSuccess) e = hipEventElapsedTime(&t, ea, eb);
     }
+    unsigned long long hticks = 0;
+    if (e == hipSuccess) e = hipMemcpy(&hticks, dticks, 8, hipMemcpyDeviceToHost);
+    if (ticks) *ticks = (double)hticks;
+    (void)hipFree(dticks);
     if (ea) (void)hipEventDestroy(ea);
     if (eb) (void)hipEventDestroy(eb);
     cleanup();

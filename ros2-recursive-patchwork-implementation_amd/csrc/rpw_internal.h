@@ -87,7 +87,7 @@ void launch_frame_setup(uint32_t* offsets, uint32_t n, uint32_t tiles, uint32_t*
 void launch_frame_copy_out(const uint8_t* labels, uint8_t* h_labels, uint32_t n, const float* res, float* h_res,
                            const rpw_frame_stats* stats, rpw_frame_stats* h_stats, const uint32_t* fit_error, hipStream_t s);
 void launch_loop_bench(const float* sx, const float* sy, const float* sz, uint8_t* mask, uint32_t* il, uint32_t n, uint32_t count,
-                       int what, int reps, uint32_t blocks, float* out, hipStream_t s);
+                       int what, int reps, uint32_t blocks, float* out, unsigned long long* ticks, hipStream_t s);
 void launch_result_record(const rpw_frame_stats* stats, int32_t* out, uint32_t n_frames, const uint32_t* fit_error, hipStream_t s);
 void launch_debug_angles(const float* x, const float* y, float* a, uint32_t n, hipStream_t s);
 void launch_debug_eig3(const float* cov9, float* normal3, uint32_t n, hipStream_t s);

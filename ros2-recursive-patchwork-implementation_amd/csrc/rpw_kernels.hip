@@ -1449,7 +1449,7 @@ __device__ __forceinline__ void srv_wait(const SrvPort& pt, uint32_t need, uint3
         seen = uni(*(volatile lds_word*)pt.cw);
         const uint32_t broken = uni(*(volatile lds_word*)pt.err);
         if ((int32_t)(seen - need) >= 0 || broken) break;          // (after one time-out nobody in the workgroup waits again)
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(0);
         if (++spins > kSrvSpinLimit) { *(volatile lds_word*)pt.err = 1u; break; }
     }
     asm volatile("" ::: "memory");
@@ -1530,6 +1530,83 @@ __device__ __attribute__((noinline)) void srv_loop(SrvShared* sv, Fit1Shared* sh
     }
 }
 
+// The server of ONE feeder (patch_fit_srv1_kernel: launches of few patches, where a patch's own time is what counts). Same
+// hand-over words, same sums as srv_loop; what differs is what a slot costs. Measured on a lone wave (tools/microbench_srv1.hip,
+// microbench_srv1b.hip): 64 dependent adds take 6.6 cycles each when the eight LDS reads of the next half slot are issued
+// TOGETHER in front of 32 uninterrupted adds, 8.0 with one read between every four adds, 10.9 with a scalar branch in the
+// middle of the slot, and a pair of exec-masked LDS stores costs ~125 cycles. So a slot here is: the published count (one
+// LDS read), eight reads, 32 adds, eight reads of the NEXT slot's first half -- speculative: whether that slot had been
+// published when they were issued is decided at the end from the count read in front of them -- 32 adds, two unmasked LDS
+// stores (lanes without a result write into a dump block), one scalar branch.
+struct Srv1Dump { uint32_t w[kWave]; float f[kWave]; };
+
+__device__ __attribute__((noinline)) void srv1_loop(SrvShared* sv, Fit1Shared* sh, Srv1Dump* dump)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4f lds_f4;
+    typedef __attribute__((address_space(3))) v4u lds_u4;
+    const int lane = threadIdx.x & 63;
+    // lane k < 6 adds row k. The lanes behind them (and the rows a pass does not use) add whatever their row of the ring holds:
+    // nobody reads those accumulators, and it keeps every address of the slot a per-lane constant plus a scalar.
+    const lds_f32* ringrow = (lds_f32*)sh->ring + (lane < 6 ? lane : 5) * kLdw;
+    volatile lds_u4* fw = (volatile lds_u4*)sv->feed[0];
+    volatile lds_word* pubw = (volatile lds_word*)&sv->feed[0][0];
+    volatile lds_word* donep = (volatile lds_word*)&sv->done;
+    volatile lds_f32* accw = lane < 6 ? (lds_f32*)&sv->acc[0][lane] : (lds_f32*)&dump->f[lane];
+    volatile lds_word* consw = lane == 0 ? (lds_word*)&sv->cons[0] : (lds_word*)&dump->w[lane];
+    uint32_t cons = 0;                                     // slots added so far (wave-uniform, like everything that decides below)
+    float acc = 0.0f;
+    v4f A[8], B[8];
+    uint32_t start = 0, stride = 0, nsm = 0;
+    const lds_f32* src = ringrow;
+    bool have = false;                                     // the first half of slot `cons` is in A (requested while the slot before it was added)
+    for (;;) {                                             // one slot per iteration
+        if (!have) {
+            // ---- nothing usable prefetched: wait for a slot (or for the feeder to leave); a pass's layout is read here ----
+            uint32_t layout;
+            for (;;) {
+                const v4u st = *fw;
+                const uint32_t done = *donep;
+                start = uni(st.y); layout = uni(st.z);
+                if ((int32_t)(uni(st.x) - cons) > 0) break;
+                if (uni(done) >= 1u) return;
+                __builtin_amdgcn_s_sleep(0);
+            }
+            stride = layout & 0xffffu; nsm = layout >> 16;
+            // (a pass begins here, never with a prefetched slot: the feeder starts the next pass only after it has seen the
+            // last slot of this one added, and by then this wave has found nothing published and is polling)
+            if (cons == start) acc = 0.0f;                         // Zero(), then +=
+            src = ringrow + ((cons - start) & nsm) * stride;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const lds_f4*>(src + 4 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) B[q] = *reinterpret_cast<const lds_f4*>(src + 32 + 4 * q);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) RPW_CHAIN4(acc, A[q])
+        __builtin_amdgcn_sched_barrier(0);
+        ++cons;
+        // The first half of the next slot, requested now whether or not that slot exists yet. The published count is read
+        // in front of it (one wave's LDS operations are performed in order): if it covers the slot, the addends just
+        // requested are the slot's -- the feeder writes a slot before it announces it. A count beyond `cons` can only belong
+        // to THIS pass (see above), so stride and nsm still hold.
+        const uint32_t pubv = *pubw;
+        src = ringrow + ((cons - start) & nsm) * stride;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const lds_f4*>(src + 4 * q);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) RPW_CHAIN4(acc, B[q])
+        __builtin_amdgcn_sched_barrier(0);
+        // every lane stores (its own address: a result word or a dump word), so no exec mask is set up
+        *accw = acc;
+        *consw = cons;
+        have = (int32_t)(uni(pubv) - cons) > 0;                    // else: poll, then read the slot's first half again
+    }
+}
+
 // feeder half of a chain sweep (the server form's w2_sweep_feed): slot s goes to ring slot s % kSrvSweepSlots once the
 // server has added slot s - kSrvSweepSlots
 template <int MODE, int IW>
@@ -1552,12 +1629,17 @@ __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t coun
     };
     const uint32_t start = srv_begin(pt, srv_layout((uint32_t)kSlotFloats, (uint32_t)kSrvSweepSlots), (uint32_t)K, lane);
     uint32_t seen = start;
-    // indices two slots ahead of the point loads, points three slots ahead of their addends
-    uint32_t i3 = index_of(3), i4 = index_of(4);
-    X3 p0 = point_of(index_of(0)), p1 = point_of(index_of(1)), p2 = point_of(index_of(2));
-    for (uint32_t s = 0; s < nslots; ++s) {
+    // Three STATIC register sets, used round robin and reloaded right after use (the loop is unrolled by three): P<k> holds
+    // the points of the next slot == k (mod 3), I<k> the indices of the slot three behind it -- points three slots ahead of
+    // their addends, indices three slots ahead of the point loads. Nothing is ever copied from one set to another: a copy
+    // reads its source, i.e. waits for a load issued one slot earlier, and the whole pipeline is then one slot deep (that
+    // was the case here until round 3: a lone patch paid a memory round trip per slot).
+    uint32_t I0 = index_of(0), I1 = index_of(1), I2 = index_of(2);
+    X3 P0 = point_of(I0), P1 = point_of(I1), P2 = point_of(I2);
+    I0 = index_of(3); I1 = index_of(4); I2 = index_of(5);
+    auto slot = [&](uint32_t s, X3& P, uint32_t& I) __attribute__((always_inline)) {
         float v[6];
-        const X3 q = p0;
+        const X3 q = P;
         if (MODE == kSweepCov) {
             const f2 dxy = f2{q.x, q.y} - f2{prm.a, prm.b};
             const float dz = q.z - prm.c;
@@ -1576,8 +1658,12 @@ __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t coun
 #pragma unroll
         for (int k = 0; k < K; ++k) dst[k * kLdw] = live ? v[k] : -0.0f;
         srv_publish(pt, start + s + 1u, lane);
-        p0 = p1; p1 = p2; p2 = point_of(i3); i3 = i4; i4 = index_of(s + 5);
-    }
+        P = point_of(I);                                      // slot s + 3
+        I = index_of(s + 6u);
+    };
+    uint32_t s = 0;
+    for (; s + 3u <= nslots; s += 3u) { slot(s, P0, I0); slot(s + 1u, P1, I1); slot(s + 2u, P2, I2); }
+    if (s < nslots) { slot(s, P0, I0); if (s + 1u < nslots) slot(s + 1u, P1, I1); }
     srv_wait(pt, start + nslots, seen);
     Sums6 out;
 #pragma unroll
@@ -2039,6 +2125,24 @@ __global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void patch_fit_srv_ke
     srv_leave(sv, lane);
 }
 
+// The same division of labour for a launch of FEW patches (one frame, a pipeline slot): one workgroup per patch, wave 0 its
+// server (srv1_loop), wave 1 the feeder that owns the patch. What counts here is the time of the slowest patch, i.e. cycles
+// per addend of one chain: 8.4-8.6 with this server, where a chain wave that meets its helper wave at a barrier per 64
+// addends (patch_fit1_kernel<2>, rounds 2's latency form) needs 10.1-10.9.
+__global__ __launch_bounds__(2 * kWave, 4) void patch_fit_srv1_kernel(DevParams p)
+{
+    __shared__ SrvShared sv;
+    __shared__ Fit1Shared sh;
+    __shared__ Srv1Dump dump;
+    srv_init(&sv);
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < kWave) { srv1_loop(&sv, &sh, &dump); return; }
+    uint32_t linear;
+    if (patch_of_item(p, blockIdx.x, lane, linear)) fit_patch<3>(p, sh, linear, lane, &sv, 0);
+    if (lane == 0 && *(volatile uint32_t*)&sv.error) atomicOr(p.work + 1, 1u);      // a wait timed out: the host reports it
+    srv_leave(&sv, lane);
+}
+
 // ------------------------------------------------------------------------------------------
 // debug kernels (test hooks)
 // ------------------------------------------------------------------------------------------
@@ -2064,7 +2168,7 @@ __global__ void debug_eig3_kernel(const float* cov, float* nrm, uint32_t n)
 // ------------------------------------------------------------------------------------------
 template <int W>
 __global__ __launch_bounds__(kFit1Threads * W, 4) void w1_loop_bench_kernel(const float* sx, const float* sy, const float* sz, uint8_t* mask,
-                                                                            uint32_t* il, uint32_t n, uint32_t count, int what, int reps, float* out)
+                                                                            uint32_t* il, uint32_t n, uint32_t count, int what, int reps, float* out, unsigned long long* ticks)
 {
     __shared__ Fit1Shared sh;
     if (W == 2 && threadIdx.x >= 64) { w2_helper_loop(&sh); return; }
@@ -2074,6 +2178,7 @@ __global__ __launch_bounds__(kFit1Threads * W, 4) void w1_loop_bench_kernel(cons
     NodeRef nd; nd.x = (g_cf32*)(sx + base); nd.y = (g_cf32*)(sy + base); nd.z = (g_cf32*)(sz + base);
     nd.m = (g_u8*)(mask + base); nd.il = (g_u32*)(il + base); nd.n = n;
     float acc = 0.0f;
+    const unsigned long long tick0 = __builtin_readcyclecounter();      // shader clock (s_memtime): the chip's clock depends on its recent load
     for (int r = 0; r < reps; ++r) {
         if (what == 6) {                                           // `count` eigenvector solves (one per refit in patch_fit), covariances of a noisy plane
             for (uint32_t i = 0; i < count; ++i) {
@@ -2092,12 +2197,12 @@ __global__ __launch_bounds__(kFit1Threads * W, 4) void w1_loop_bench_kernel(cons
         }
     }
     if (W == 2) { if (lane == 0) sh.cmd[0] = (uint32_t)kCmdExit; w2_barrier(); }
-    if (lane == 0) out[blockIdx.x] = acc;
+    if (lane == 0) { out[blockIdx.x] = acc; if (blockIdx.x == 0) ticks[0] = __builtin_readcyclecounter() - tick0; }
 }
 
 // the same loops in the chain-server form: workgroup b's feeder f runs them on node b * kSrvFeeders + f
 __global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void srv_loop_bench_kernel(const float* sx, const float* sy, const float* sz, uint8_t* mask,
-                                                                                     uint32_t* il, uint32_t n, uint32_t count, int what, int reps, uint32_t nodes, float* out)
+                                                                                     uint32_t* il, uint32_t n, uint32_t count, int what, int reps, uint32_t nodes, float* out, unsigned long long* ticks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char srv_lds[];
     SrvShared* sv = reinterpret_cast<SrvShared*>(srv_lds);
@@ -2112,6 +2217,7 @@ __global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void srv_loop_bench_k
         NodeRef nd; nd.x = (g_cf32*)(sx + base); nd.y = (g_cf32*)(sy + base); nd.z = (g_cf32*)(sz + base);
         nd.m = (g_u8*)(mask + base); nd.il = (g_u32*)(il + base); nd.n = n;
         float acc = 0.0f;
+        const unsigned long long tick0 = __builtin_readcyclecounter();
         for (int r = 0; r < reps; ++r) {
             if (what < 16) {
                 SweepPrm prm; prm.a = 0.25f + acc * 0.0f; prm.b = -0.5f; prm.c = 0.125f; prm.d = 0.0f; prm.e = 0.0f; prm.f = 1.0f;
@@ -2123,9 +2229,49 @@ __global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void srv_loop_bench_k
                 else { const FusedOut o = srv_fused_pass(nd, what - 16, mp, ring, sv, f); acc += (float)o.count + o.sx * 0.0f; }
             }
         }
-        if (lane == 0) out[node] = acc + (float)sv->error * 1.0e30f;
+        if (lane == 0) { out[node] = acc + (float)sv->error * 1.0e30f; if (node == 0) ticks[0] = __builtin_readcyclecounter() - tick0; }
     }
     srv_leave(sv, lane);
+}
+
+// ... and with one server per node: workgroup b = server wave + the feeder of node b
+__global__ __launch_bounds__(2 * kWave, 4) void srv1_loop_bench_kernel(const float* sx, const float* sy, const float* sz, uint8_t* mask,
+                                                                      uint32_t* il, uint32_t n, uint32_t count, int what, int reps, float* out, unsigned long long* ticks)
+{
+    __shared__ SrvShared sv;
+    __shared__ Fit1Shared sh;
+    __shared__ Srv1Dump dump;
+    srv_init(&sv);
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < kWave) { srv1_loop(&sv, &sh, &dump); return; }
+    lds_f32* ring = (lds_f32*)sh.ring;
+    const size_t base = (size_t)blockIdx.x * n;
+    NodeRef nd; nd.x = (g_cf32*)(sx + base); nd.y = (g_cf32*)(sy + base); nd.z = (g_cf32*)(sz + base);
+    nd.m = (g_u8*)(mask + base); nd.il = (g_u32*)(il + base); nd.n = n;
+    float acc = 0.0f;
+    const unsigned long long tick0 = __builtin_readcyclecounter();
+    for (int r = 0; r < reps; ++r) {
+        if (what == 7) {                                           // the server alone: `count` addends published at once (whatever the ring holds)
+            const SrvPort pt = srv_port(&sv, 0);
+            const uint32_t nslots = (count + kWave - 1) / kWave;
+            const uint32_t start = srv_begin(pt, srv_layout((uint32_t)kSlotFloats, (uint32_t)kSrvSweepSlots), 6u, lane);
+            uint32_t seen = start;
+            for (int i = lane; i < kRingFloats; i += kWave) sh.ring[i] = 1.0f + (float)i * 1.0e-3f;      // ordinary numbers
+            wave_sync();
+            srv_publish(pt, start + nslots, lane);
+            srv_wait(pt, start + nslots, seen);
+        } else if (what < 16) {
+            SweepPrm prm; prm.a = 0.25f + acc * 0.0f; prm.b = -0.5f; prm.c = 0.125f; prm.d = 0.0f; prm.e = 0.0f; prm.f = 1.0f;
+            const Sums6 v = srv_chain_sweep(nd, count, what, prm, ring, &sv, 0);
+            acc += v.v[0];
+        } else {
+            MaskPrm mp; mp.cx = 0.0f; mp.cy = 0.0f; mp.cz = acc * 0.0f; mp.nx = 0.0f; mp.ny = 0.0f; mp.nz = 1.0f; mp.thr = 0.6f;
+            if (what == 18) { const MaskOut o = w1_mask_pass(nd, kMaskOlder, mp); acc += (float)o.count; }
+            else { const FusedOut o = srv_fused_pass(nd, what - 16, mp, ring, &sv, 0); acc += (float)o.count + o.sx * 0.0f; }
+        }
+    }
+    if (lane == 0) { out[blockIdx.x] = acc + (float)sv.error * 1.0e30f; if (blockIdx.x == 0) ticks[0] = __builtin_readcyclecounter() - tick0; }
+    srv_leave(&sv, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2223,9 +2369,11 @@ void launch_fit(const DevParams& p, hipStream_t s)
         const size_t per = (160u * 1024u) / (size_t)k, stat = sizeof(Fit1Shared) + 64;
         return per > stat ? ((per - stat) & ~(size_t)255) : (size_t)0;
     }();
-    // RPW_FIT_WAVES=1|2|3 forces a form (tests, A/B measurements): one wave per patch, chain + helper wave, chain server.
+    // RPW_FIT_WAVES=1|2|3|4 forces a form (tests, A/B measurements): one wave per patch, chain + helper wave, chain server,
+    // one server per patch.
     static const int forced = [] { const char* e = getenv("RPW_FIT_WAVES"); return e ? atoi(e) : 0; }();
     if (forced == 1) { hipLaunchKernelGGL(patch_fit1_kernel<1>, dim3(grid), dim3(kFit1Threads), pad, s, p); return; }
+    if (forced == 4) { hipLaunchKernelGGL(patch_fit_srv1_kernel, dim3(grid), dim3(2 * kWave), 0, s, p); return; }
     // few patches in the launch (a frame or a few: the host-pointer path) -> a chain wave + a helper wave per patch, the form
     // with the shortest time per patch; a batch -> the chain-server form, the one with the fewest instructions per point
     if (forced == 2 || (forced == 0 && grid <= 8u * 256u)) { hipLaunchKernelGGL(patch_fit1_kernel<2>, dim3(grid), dim3(2 * kFit1Threads), pad, s, p); return; }
@@ -2252,18 +2400,19 @@ void launch_frame_copy_out(const uint8_t* labels, uint8_t* h_labels, uint32_t n,
     hipLaunchKernelGGL(frame_copy_out_kernel, dim3(blocks), dim3(256), 0, s, labels, h_labels, n, res, h_res, stats, h_stats, fit_error);
 }
 void launch_loop_bench(const float* sx, const float* sy, const float* sz, uint8_t* mask, uint32_t* il, uint32_t n, uint32_t count,
-                       int what, int reps, uint32_t blocks, float* out, hipStream_t s)
+                       int what, int reps, uint32_t blocks, float* out, unsigned long long* ticks, hipStream_t s)
 {
-    const int w = what >= 64 ? 3 : (what >= 32 ? 2 : 1);      // what + 32: the same loop in the two-wave form, + 64: chain-server form
+    const int w = 1 + (what >> 5);      // what + 32: the same loop in the two-wave form, + 64: chain-server form, + 96: one server per node
     what &= 31;
+    if (w == 4) { hipLaunchKernelGGL(srv1_loop_bench_kernel, dim3(blocks), dim3(2 * kWave), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out, ticks); return; }
     if (w == 3) {
         allow_srv_lds(reinterpret_cast<const void*>(srv_loop_bench_kernel));
         const uint32_t wgs = (blocks + (uint32_t)kSrvFeeders - 1u) / (uint32_t)kSrvFeeders;
-        hipLaunchKernelGGL(srv_loop_bench_kernel, dim3(wgs), dim3(kWave * (1 + kSrvFeeders)), kSrvLdsBytes, s, sx, sy, sz, mask, il, n, count, what, reps, blocks, out);
+        hipLaunchKernelGGL(srv_loop_bench_kernel, dim3(wgs), dim3(kWave * (1 + kSrvFeeders)), kSrvLdsBytes, s, sx, sy, sz, mask, il, n, count, what, reps, blocks, out, ticks);
         return;
     }
-    if (w == 2) hipLaunchKernelGGL(w1_loop_bench_kernel<2>, dim3(blocks), dim3(2 * kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out);
-    else        hipLaunchKernelGGL(w1_loop_bench_kernel<1>, dim3(blocks), dim3(kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out);
+    if (w == 2) hipLaunchKernelGGL(w1_loop_bench_kernel<2>, dim3(blocks), dim3(2 * kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out, ticks);
+    else        hipLaunchKernelGGL(w1_loop_bench_kernel<1>, dim3(blocks), dim3(kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out, ticks);
 }
 void launch_debug_angles(const float* x, const float* y, float* a, uint32_t n, hipStream_t s)
 {

@@ -55,7 +55,7 @@ print("FORM_OK", %(form)s, n)
 """
 
 
-@pytest.mark.parametrize("form", [1, 2, 3])
+@pytest.mark.parametrize("form", [1, 2, 3, 4])
 def test_every_form_of_patch_fit_equals_the_oracle(form):
     env = dict(os.environ, RPW_FIT_WAVES=str(form))
     out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, form=form)], env=env, capture_output=True, text=True, timeout=900)
