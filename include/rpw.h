@@ -248,8 +248,8 @@ rpw_status  rpw_debug_angles(rpw_handle* h, const float* x, const float* y, floa
 rpw_status  rpw_debug_eig3(rpw_handle* h, const float* cov9, float* normal3, uint32_t n);
 /* Micro-benchmark of the two loops the plane-fit kernel lives in, on a synthetic node of n slots of which inlier_pct %
  * are inliers, one node per workgroup, `blocks` workgroups, `reps` passes each: what = 0..5 chain sweeps (centroid,
- * covariance, residual, range, xy, variance), 16..18 fused / mask passes (seed, plane, older); + 32: the same loop in the
- * two-wave form (chain wave + helper wave). ms = device time of the launch. */
+ * covariance, residual, range, xy, variance), 16..18 fused / mask passes (seed, plane, older); + 64: the same loop in the
+ * chain-server form (seven nodes per server wave), + 96: with a server wave per node. ms = device time of the launch. */
 rpw_status  rpw_debug_loop_bench(rpw_handle* h, int what, uint32_t n, uint32_t inlier_pct, int reps, uint32_t blocks, double* ms);
 /* The same, and the shader-clock ticks (s_memtime) node 0's owner wave spent in its `reps` passes: the chip's clock follows
  * its recent load, so cycles -- not wall time -- compare the loops of a LONE patch. ticks may be NULL. */

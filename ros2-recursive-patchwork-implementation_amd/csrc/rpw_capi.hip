@@ -914,7 +914,7 @@ rpw_status rpw_debug_loop_bench_ticks(rpw_handle* h, int what, uint32_t n, uint3
     if (!h || !ms || n == 0 || blocks == 0 || reps <= 0 || inlier_pct > 100) return RPW_ERR_INVALID;
     if ((uint64_t)n * blocks > (1ull << 28)) return fail(h, RPW_ERR_CAPACITY, "loop bench: n * blocks too large");
     const int base_what = what & 31;
-    if ((what & ~127) || !((base_what >= 0 && base_what <= 7) || (base_what >= 16 && base_what <= 18)))
+    if ((what & ~127) || (what & 96) == 32 || !((base_what >= 0 && base_what <= 7) || (base_what >= 16 && base_what <= 18)))
         return fail(h, RPW_ERR_INVALID, "loop bench: unknown loop %d", what);
     RPW_HIP(h, hipSetDevice(h->device));
     const size_t total = (size_t)n * blocks;

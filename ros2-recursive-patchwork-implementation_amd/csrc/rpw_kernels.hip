@@ -10,9 +10,9 @@
 //   K3 patch_fit       fitPlaneAndSplit / fitPlanePCA / computeCentroid / computeCovariance /
 //                      Eigen solve / computePlaneDistances / mask compare / split + recursion
 //                      (recursive_patchwork.cpp:77-308). One OWNER wave per (frame, patch) runs the passes; the dependent
-//                      adds of its sequential sums run on the owner itself (patch_fit1_kernel<1>), on the owner while a
-//                      helper wave feeds it (patch_fit1_kernel<2>, launches of few patches), or on a server wave that
-//                      adds for seven owners at once (patch_fit_srv_kernel, batches) -- see launch_fit and DESIGN.md section 4
+//                      adds of its sequential sums run on the owner itself (patch_fit1_kernel), on a server wave that adds
+//                      for seven owners at once (patch_fit_srv_kernel, batches), or on a server wave of the patch's own
+//                      (patch_fit_srv1_kernel, launches of few patches) -- see launch_fit and DESIGN.md section 4
 //
 // Exactness: every sum the reference accumulates sequentially in binary32 (centroid,
 // covariance, residual, mean distance, variance) is accumulated here in the same order
@@ -470,10 +470,6 @@ struct Fit1Shared {
     __attribute__((aligned(16))) float ring[kRingFloats];              // sweeps: kW1Ring * kSlotFloats floats; fused pass: kFSlots * kFSlotFloats
     uint32_t hist[256];
     uint32_t stk[3 * kStackDepth];
-    // two-wave form only: the command the chain wave hands the helper wave, and the fused pass's hand-off words
-    uint32_t cmd[24];
-    uint32_t fcur[2];                  // inliers written up to the end of round r, in fcur[r & 1]
-    uint32_t fflags[2];                // changed / differs-from-the-mask-before, of the whole pass
 };
 static_assert(kW1Ring * kSlotFloats <= kRingFloats, "the sweep ring must fit");
 
@@ -490,8 +486,8 @@ struct W1 {
 struct P4 { float x, y, z; uint32_t m; };
 
 // Ordering INSIDE one wave (a lane reads what another lane of the same wave wrote, in LDS or in global memory through the
-// CU's L1): earlier accesses complete before later ones start. No s_barrier: in the two-wave form these phases run on
-// the chain wave alone while the helper wave is parked at a barrier of its own.
+// CU's L1): earlier accesses complete before later ones start. No s_barrier: the waves of a workgroup run independent
+// control flow (a server wave and its patch owners).
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
 typedef __attribute__((address_space(3))) float lds_f32;
@@ -724,7 +720,6 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
 {
     typedef __attribute__((address_space(1))) char g_char;
     typedef float v4f __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) v4f lds_f4;
     g_char* il = reinterpret_cast<g_char*>(nd.il);
     const uint32_t n = nd.n;
     const uint32_t nfull = n / kWave;
@@ -993,309 +988,6 @@ __device__ __attribute__((noinline)) Sums6 w1_chain_sweep(NodeRef nd_in, uint32_
     return out;
 }
 
-// ==========================================================================================
-// TWO-WAVE FORM of the passes (patch_fit kernel with a helper wave). A lone wave pays ~4.7 cycles for every vector
-// instruction it executes besides the chain's adds, wherever it stands (tools/microbench_fill.hip: nothing but LDS,
-// scalar and memory instructions rides in a dependent add's shadow); a patch's latency is the chain's 8.2 cycles per
-// addend PLUS all the arithmetic that feeds it. Here that arithmetic moves to a second wave:
-//   wave 0 (chain wave): everything as in the single-wave form, except that in the two chained passes it only reads the
-//                        ring and adds;
-//   wave 1 (helper):     parked at a barrier; for a chained pass it receives a command (LDS) and plays the feeding half --
-//                        loads, addends, ring writes (sweep), or loads, predicate, mask bytes, index list, ring writes
-//                        (fused pass) -- one step ahead of the chain, with ONE s_barrier per step (64 addends of a
-//                        sweep, two chunks of a fused pass). The feeding half needs ~40 vector instructions where the
-//                        chain needs 64 x 8.2 cycles, so the chain never waits (round 1's producer needed ~170).
-// Both halves execute the same number of barriers by construction (it depends on the element count only).
-// ==========================================================================================
-enum { kCmdExit = 0, kCmdSweep = 1, kCmdFused = 2 };
-constexpr int kFusedRoundChunks = 2;     // two chunks per round: at most 3 + 128 + 128 addends wait in the 512-entry ring
-
-__device__ __forceinline__ void w2_barrier() { __syncthreads(); }
-// The per-step rendezvous of the two waves: LDS traffic only. (__syncthreads() also waits for vmcnt(0): the helper's
-// global loads, requested four chunks / three slots ahead, would be drained at every step and every step would pay a
-// full memory round trip -- measured: 12 cycles per point whatever the two halves did.)
-__device__ __forceinline__ void w2_step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// feeding half of a chain sweep: slot s is produced in step s; the chain adds slot s - 2 meanwhile and has prefetched s - 1
-template <int MODE, int IW>
-__device__ __forceinline__ void w2_sweep_feed(const NodeRef& nd, uint32_t count, const SweepPrm& prm, lds_f32* ring, int lane)
-{
-    constexpr int K = SweepRows<MODE>::K;
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    typedef __attribute__((address_space(1))) const char g_cchar;
-    g_cchar* il = reinterpret_cast<g_cchar*>(nd.il);
-    const uint32_t nslots = (count + kWave - 1) / kWave;
-    const uint32_t last = count - 1u;
-    auto index_of = [&](uint32_t u) -> uint32_t {
-        const uint32_t j = u * kWave + lane, jc = j < last ? j : last;
-        return IW ? il_load<(IW ? IW : 4)>(il, jc) : jc;
-    };
-    auto point_of = [&](uint32_t idx) -> X3 {
-        X3 q; q.x = ldg_f32(nd.x, idx); q.y = ldg_f32(nd.y, idx);
-        q.z = (MODE == kSweepXYZ || MODE == kSweepCov || MODE == kSweepDist) ? ldg_f32(nd.z, idx) : 0.0f;
-        return q;
-    };
-    // indices two slots ahead of the point loads, points three slots ahead of their addends
-    uint32_t i3 = index_of(3), i4 = index_of(4);
-    X3 p0 = point_of(index_of(0)), p1 = point_of(index_of(1)), p2 = point_of(index_of(2));
-    for (uint32_t s = 0; s < nslots + 2u; ++s) {
-        if (s < nslots) {
-            float v[6];
-            const X3 q = p0;
-            if (MODE == kSweepCov) {
-                const f2 dxy = f2{q.x, q.y} - f2{prm.a, prm.b};
-                const float dz = q.z - prm.c;
-                const f2 a = dxy * f2{dxy.x, dxy.x};            // dx*dx, dy*dx
-                const f2 b = f2{dxy.y, dz} * f2{dxy.y, dxy.x};  // dy*dy, dz*dx
-                const f2 c = f2{dz, dz} * f2{dxy.y, dz};        // dz*dy, dz*dz
-                v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
-            } else if (MODE == kSweepXYZ) { v[0] = q.x; v[1] = q.y; v[2] = q.z; }
-            else if (MODE == kSweepDist)  { v[0] = plane_dist(q.x, q.y, q.z, prm.a, prm.b, prm.c, prm.d, prm.e, prm.f); }
-            else if (MODE == kSweepRange) { v[0] = sqrt_rn(q.x * q.x + q.y * q.y); }
-            else if (MODE == kSweepXY)    { v[0] = q.x; v[1] = q.y; }
-            else { const float dx = q.x - prm.a, dy = q.y - prm.b; v[0] = dx * dx; v[1] = dy * dy; }
-            lds_f32* dst = ring + (s % (uint32_t)kW1Ring) * kSlotFloats + lane;
-            const bool live = s * kWave + lane < count;           // columns past the end: -0.0f, the exact additive identity
-#pragma unroll
-            for (int k = 0; k < K; ++k) dst[k * kLdw] = live ? v[k] : -0.0f;
-            p0 = p1; p1 = p2; p2 = point_of(i3); i3 = i4; i4 = index_of(s + 5);
-        }
-        w2_step_barrier();
-    }
-}
-
-// chain half of a chain sweep: K sequential sums, accumulator k in lane k; the same steps and barriers as w2_sweep_feed
-__device__ __forceinline__ float w2_sweep_chain(uint32_t count, int K, lds_f32* ring, int lane)
-{
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) v4f lds_f4;
-    const uint32_t nslots = (count + kWave - 1) / kWave;
-    const int row = lane < K ? lane : K - 1;
-    const lds_f32* rowp = ring + row * kLdw;
-    float acc = 0.0f;                                              // Zero(), then += in element order
-    v4f A[8], B[8];
-    w2_step_barrier();                                                  // step 0: slot 0 is being produced
-#pragma unroll
-    for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const lds_f4*>(rowp + 4 * q);      // first half of slot 0
-    w2_step_barrier();                                                  // step 1: slot 1 is being produced
-#define RPW_W2_SLOT(RS) {                                                                                   \
-        const lds_f32* cur = rowp + (RS) * kSlotFloats + 32;                                                \
-        const lds_f32* nxt = rowp + (((RS) + 1) % kW1Ring) * kSlotFloats;                                   \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q) { B[q] = *reinterpret_cast<const lds_f4*>(cur + 4 * q); RPW_CHAIN4(acc, A[q]) __builtin_amdgcn_sched_barrier(0); } \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q) { A[q] = *reinterpret_cast<const lds_f4*>(nxt + 4 * q); RPW_CHAIN4(acc, B[q]) __builtin_amdgcn_sched_barrier(0); } \
-        w2_step_barrier();                                                                                       \
-    }
-    for (uint32_t t = 0; t < nslots; t += 3) {                     // step t + 2: slot t is added, slot t + 2 is being produced
-        RPW_W2_SLOT(0)
-        if (t + 1 >= nslots) break;
-        RPW_W2_SLOT(1)
-        if (t + 2 >= nslots) break;
-        RPW_W2_SLOT(2)
-    }
-#undef RPW_W2_SLOT
-    return acc;
-}
-
-// rounds of the fused pass: R rounds of kFusedRoundChunks full chunks, then single full chunks, then the partial chunk
-__device__ __forceinline__ uint32_t w2_fused_rounds(uint32_t n)
-{
-    const uint32_t nfull = n / kWave;
-    return nfull / kFusedRoundChunks + nfull % kFusedRoundChunks + ((nfull * kWave < n) ? 1u : 0u);
-}
-
-// feeding half of the fused pass: predicate, mask byte, index list, centroid addends into the ring; after every round the
-// number of inliers so far is published, then the round's barrier
-template <int MODE, int IW>
-__device__ __forceinline__ void w2_fused_feed(const NodeRef& nd, const MaskPrm& prm, lds_f32* ring, uint32_t* fcur, uint32_t* fflags, int lane)
-{
-    typedef __attribute__((address_space(1))) char g_char;
-    g_char* il = reinterpret_cast<g_char*>(nd.il);
-    const uint32_t n = nd.n;
-    const uint32_t nfull = n / kWave;
-    uint32_t cursor = 0, round = 0;
-    bool changed = false, differs_prev = false;
-    auto step = [&](const P4& r, uint32_t c, auto full) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full)::value;
-        const uint32_t i = c * kWave + lane;
-        const bool ok = FULL || i < n;
-        bool in;
-        if (MODE == kMaskPlane) {
-            const float d = plane_dist(r.x, r.y, r.z, prm.cx, prm.cy, prm.cz, prm.nx, prm.ny, prm.nz);
-            in = d < prm.thr;
-            const bool old = r.m & 1u, prev = (r.m >> 1) & 1u;
-            changed |= ok && (in != old);
-            differs_prev |= ok && (in != prev);
-            const uint8_t nb = (uint8_t)((in ? 1u : 0u) | ((r.m & 0x7fu) << 1));
-            if (FULL) nd.m[i] = nb; else if (ok) nd.m[i] = nb;
-        } else {
-            in = r.z < prm.thr;
-            if (FULL) nd.m[i] = in ? 1 : 0; else if (ok) nd.m[i] = in ? 1 : 0;
-        }
-        in = in && ok;
-        const unsigned long long m = ballot64(in);
-        const uint32_t p = cursor + (uint32_t)mbcnt64(m);
-        const uint32_t sel = 0u - (uint32_t)in;
-        const uint32_t ip = (p & sel) | ((n - 1u) & ~sel);
-        if (FULL) il_store<IW>(il, ip, i);
-        else if (ok) il_store<IW>(il, ip, i);
-        const uint32_t lp = (fused_ring_pos(p) & sel) | (((uint32_t)kFDump + (uint32_t)lane) & ~sel);
-        lds_f32* w = ring + lp;
-        w[0] = r.x; w[kLdw] = r.y; w[2 * kLdw] = r.z;
-        cursor += (uint32_t)__popcll(m);
-    };
-    auto end_round = [&]() __attribute__((always_inline)) {
-        if (lane == 0) ((lds_word*)fcur)[round & 1u] = cursor;     // (an LDS store, not a flat one: flat stores count on vmcnt too)
-        ++round;
-        w2_step_barrier();
-    };
-    uint32_t c = 0;
-    if (nfull >= 4) {
-        P4 r0 = w1_load(nd, 0 * kWave + lane), r1 = w1_load(nd, 1 * kWave + lane), r2 = w1_load(nd, 2 * kWave + lane), r3 = w1_load(nd, 3 * kWave + lane);
-        const uint32_t lastfull = (nfull - 1u) * kWave;
-        // two rounds of two chunks, four register sets; the first pair of rounds is peeled out of the loop (the wait
-        // counts of a loop must also hold for the way it is entered: entered straight from the back-to-back prologue
-        // loads, its head got a vmcnt(0) and every pair of rounds paid a full memory round trip)
-        auto two_rounds = [&]() __attribute__((always_inline)) {
-            const uint32_t b4 = (c + 4) * kWave, b5 = b4 + kWave, b6 = b5 + kWave, b7 = b6 + kWave;
-            __builtin_amdgcn_sched_barrier(0);
-            step(r0, c, yes());     r0 = w1_load(nd, (b4 < lastfull ? b4 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
-            step(r1, c + 1, yes()); r1 = w1_load(nd, (b5 < lastfull ? b5 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
-            end_round();
-            step(r2, c + 2, yes()); r2 = w1_load(nd, (b6 < lastfull ? b6 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
-            step(r3, c + 3, yes()); r3 = w1_load(nd, (b7 < lastfull ? b7 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
-            end_round();
-            c += 4;
-        };
-        two_rounds();
-        while (c + 4 <= nfull) two_rounds();
-    }
-    // what is left: 0..3 full chunks, in rounds of two, then of one
-    for (; c + 2 <= nfull; c += 2) {
-        const P4 ra = w1_load(nd, c * kWave + lane), rb = w1_load(nd, (c + 1) * kWave + lane);
-        step(ra, c, yes()); step(rb, c + 1, yes());
-        end_round();
-    }
-    for (; c < nfull; ++c) {
-        const P4 r = w1_load(nd, c * kWave + lane);
-        step(r, c, yes());
-        end_round();
-    }
-    if (nfull * kWave < n) {
-        const uint32_t i = nfull * kWave + lane;
-        const P4 r = w1_load(nd, i < n ? i : n - 1u);
-        step(r, nfull, no());
-        end_round();
-    }
-    const bool ch = ballot64(changed) != 0ull, df = ballot64(differs_prev) != 0ull;
-    if (lane == 0) { ((lds_word*)fflags)[0] = ch ? 1u : 0u; ((lds_word*)fflags)[1] = df ? 1u : 0u; }
-    w2_barrier();                                                  // the final barrier, a full one: the mask bytes and the index list are written
-}
-
-// chain half of the fused pass: round r adds the slots the rounds before it completed; R + 1 barriers like the feeding half.
-// (While round r is written, the slots being read start at most 4 slots behind the write position: 8 slots are enough.)
-__device__ __forceinline__ FusedOut w2_fused_chain(uint32_t n, lds_f32* ring, const uint32_t* fcur, const uint32_t* fflags, int lane)
-{
-    const uint32_t R = w2_fused_rounds(n);
-    FusedChain ch;
-    const int row = lane < 3 ? lane : 2;
-    const lds_f32* rowp = ring + row * kLdw;
-    const lds_word* lcur = (const lds_word*)fcur;
-    w2_step_barrier();                                             // round 0 is being produced
-    for (uint32_t r = 1; r < R; ++r) {                             // round r is being produced; rounds < r are complete
-        ch.consume(rowp, uni(lcur[(r - 1u) & 1u]) >> 6);
-        w2_step_barrier();
-    }
-    const uint32_t cursor = uni(lcur[(R - 1u) & 1u]);
-    ch.consume(rowp, cursor >> 6);                                 // the helper is finishing (flags, final barrier)
-    w2_barrier();
-    ch.finish(ring, rowp, cursor, lane);                           // everything is produced: the last slot, padded
-    FusedOut o;
-    o.count = cursor; o.changed = ((const lds_word*)fflags)[0]; o.differs_prev = ((const lds_word*)fflags)[1];
-    o.sx = __shfl(ch.acc, 0); o.sy = __shfl(ch.acc, 1); o.sz = __shfl(ch.acc, 2);
-    return o;
-}
-
-// The helper wave: waits for commands, plays the feeding half of the pass, until it is told to leave.
-__device__ __attribute__((noinline)) void w2_helper_loop(Fit1Shared* shp)
-{
-    const int lane = threadIdx.x & 63;
-    lds_f32* ring = (lds_f32*)shp->ring;
-    for (;;) {
-        w2_barrier();                                              // a command is there
-        const uint32_t* c = shp->cmd;
-        const uint32_t op = uni(c[0]);
-        if (op == (uint32_t)kCmdExit) break;
-        const uint32_t mode = uni(c[1]), count = uni(c[2]);
-        NodeRef nd;
-        nd.x = (g_cf32*)(((unsigned long long)uni(c[5]) << 32) | uni(c[4]));
-        nd.y = (g_cf32*)(((unsigned long long)uni(c[7]) << 32) | uni(c[6]));
-        nd.z = (g_cf32*)(((unsigned long long)uni(c[9]) << 32) | uni(c[8]));
-        nd.m = (g_u8*)(((unsigned long long)uni(c[11]) << 32) | uni(c[10]));
-        nd.il = (g_u32*)(((unsigned long long)uni(c[13]) << 32) | uni(c[12]));
-        nd.n = uni(c[3]);
-        const bool narrow = nd.n <= 65536u;
-        if (op == (uint32_t)kCmdSweep) {
-            SweepPrm prm; prm.a = uni(__uint_as_float(c[14])); prm.b = uni(__uint_as_float(c[15])); prm.c = uni(__uint_as_float(c[16]));
-            prm.d = uni(__uint_as_float(c[17])); prm.e = uni(__uint_as_float(c[18])); prm.f = uni(__uint_as_float(c[19]));
-            switch (mode) {
-            case kSweepCov:   if (narrow) w2_sweep_feed<kSweepCov, 2>(nd, count, prm, ring, lane); else w2_sweep_feed<kSweepCov, 4>(nd, count, prm, ring, lane); break;
-            case kSweepXYZ:   if (narrow) w2_sweep_feed<kSweepXYZ, 2>(nd, count, prm, ring, lane); else w2_sweep_feed<kSweepXYZ, 4>(nd, count, prm, ring, lane); break;
-            case kSweepDist:  if (narrow) w2_sweep_feed<kSweepDist, 2>(nd, count, prm, ring, lane); else w2_sweep_feed<kSweepDist, 4>(nd, count, prm, ring, lane); break;
-            case kSweepRange: w2_sweep_feed<kSweepRange, 0>(nd, count, prm, ring, lane); break;
-            case kSweepXY:    w2_sweep_feed<kSweepXY, 0>(nd, count, prm, ring, lane); break;
-            default:          w2_sweep_feed<kSweepVarXY, 0>(nd, count, prm, ring, lane); break;
-            }
-        } else {
-            MaskPrm mp; mp.cx = uni(__uint_as_float(c[14])); mp.cy = uni(__uint_as_float(c[15])); mp.cz = uni(__uint_as_float(c[16]));
-            mp.nx = uni(__uint_as_float(c[17])); mp.ny = uni(__uint_as_float(c[18])); mp.nz = uni(__uint_as_float(c[19])); mp.thr = uni(__uint_as_float(c[20]));
-            if (mode == (uint32_t)kMaskPlane) { if (narrow) w2_fused_feed<kMaskPlane, 2>(nd, mp, ring, shp->fcur, shp->fflags, lane); else w2_fused_feed<kMaskPlane, 4>(nd, mp, ring, shp->fcur, shp->fflags, lane); }
-            else { if (narrow) w2_fused_feed<kMaskSeed, 2>(nd, mp, ring, shp->fcur, shp->fflags, lane); else w2_fused_feed<kMaskSeed, 4>(nd, mp, ring, shp->fcur, shp->fflags, lane); }
-        }
-    }
-}
-
-// chain-wave side: hand the helper a command, then run the chain half. (The node's pointers travel through LDS.)
-__device__ __forceinline__ void w2_post(Fit1Shared* shp, int lane, uint32_t op, uint32_t mode, uint32_t count, const NodeRef& nd, const float* f7)
-{
-    if (lane == 0) {
-        uint32_t* c = shp->cmd;
-        c[0] = op; c[1] = mode; c[2] = count; c[3] = nd.n;
-        const unsigned long long px = (unsigned long long)nd.x, py = (unsigned long long)nd.y, pz = (unsigned long long)nd.z,
-                                 pm = (unsigned long long)nd.m, pi = (unsigned long long)nd.il;
-        c[4] = (uint32_t)px; c[5] = (uint32_t)(px >> 32); c[6] = (uint32_t)py; c[7] = (uint32_t)(py >> 32);
-        c[8] = (uint32_t)pz; c[9] = (uint32_t)(pz >> 32); c[10] = (uint32_t)pm; c[11] = (uint32_t)(pm >> 32);
-        c[12] = (uint32_t)pi; c[13] = (uint32_t)(pi >> 32);
-        for (int k = 0; k < 7; ++k) c[14 + k] = __float_as_uint(f7[k]);
-    }
-    w2_barrier();                                                  // (waits for the stores above: the helper reads them behind it)
-}
-
-__device__ __attribute__((noinline)) Sums6 w2_chain_sweep(Fit1Shared* shp, NodeRef nd, uint32_t count, int mode, SweepPrm prm)
-{
-    const int lane = threadIdx.x & 63;
-    Sums6 out;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) out.v[k] = 0.0f;
-    count = uni(count);
-    if (count == 0) return out;
-    const float f7[7] = {prm.a, prm.b, prm.c, prm.d, prm.e, prm.f, 0.0f};
-    const int m = (int)uni((uint32_t)mode);
-    w2_post(shp, lane, kCmdSweep, (uint32_t)m, count, nd, f7);
-    const int K = m == kSweepCov ? 6 : (m == kSweepXYZ ? 3 : ((m == kSweepXY || m == kSweepVarXY) ? 2 : 1));
-    const float acc = w2_sweep_chain(count, K, (lds_f32*)shp->ring, lane);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) out.v[k] = __shfl(acc, k);
-    return out;
-}
-
-__device__ __attribute__((noinline)) FusedOut w2_fused_pass(Fit1Shared* shp, NodeRef nd, int mode, MaskPrm prm)
-{
-    const int lane = threadIdx.x & 63;
-    const float f7[7] = {prm.cx, prm.cy, prm.cz, prm.nx, prm.ny, prm.nz, prm.thr};
-    w2_post(shp, lane, kCmdFused, uni((uint32_t)mode), 0u, nd, f7);
-    return w2_fused_chain(uni(nd.n), (lds_f32*)shp->ring, shp->fcur, shp->fflags, lane);
-}
-
 // exact order statistic, single wave (see select_rank)
 __device__ __attribute__((noinline)) float w1_select_rank(W1 cx, uint32_t s, uint32_t n, int axis, uint32_t k)
 {
@@ -1544,7 +1236,6 @@ __device__ __attribute__((noinline)) void srv1_loop(SrvShared* sv, Fit1Shared* s
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) v4f lds_f4;
     typedef __attribute__((address_space(3))) v4u lds_u4;
     const int lane = threadIdx.x & 63;
     // lane k < 6 adds row k. The lanes behind them (and the rows a pass does not use) add whatever their row of the ring holds:
@@ -1561,6 +1252,20 @@ __device__ __attribute__((noinline)) void srv1_loop(SrvShared* sv, Fit1Shared* s
     uint32_t start = 0, stride = 0, nsm = 0;
     const lds_f32* src = ringrow;
     bool have = false;                                     // the first half of slot `cons` is in A (requested while the slot before it was added)
+    // The sixteen reads of a slot are written as inline assembly so that the next slot's first half can be read INTO the
+    // registers the adds of this slot's first half have just released (a tied operand): left to the register allocator, the
+    // loop-carried half went to fresh registers and was copied back by sixteen v_mov_b64 at the end of every slot (~130 cycles).
+    // The compiler does not count these reads, so the waits for them are written out as well; its own waits (for the reads it
+    // does see) can only wait longer, never shorter: LDS operations of a wave return in order.
+#define RPW_LDS_READ8(DST, CONSTRAINT, ADDR, OFF)                                                                                         \
+    asm volatile("ds_read_b128 %0, %8 offset:" #OFF "+0\n\tds_read_b128 %1, %8 offset:" #OFF "+16\n\tds_read_b128 %2, %8 offset:" #OFF "+32\n\t" \
+                 "ds_read_b128 %3, %8 offset:" #OFF "+48\n\tds_read_b128 %4, %8 offset:" #OFF "+64\n\tds_read_b128 %5, %8 offset:" #OFF "+80\n\t" \
+                 "ds_read_b128 %6, %8 offset:" #OFF "+96\n\tds_read_b128 %7, %8 offset:" #OFF "+112"                                         \
+                 : CONSTRAINT(DST[0]), CONSTRAINT(DST[1]), CONSTRAINT(DST[2]), CONSTRAINT(DST[3]), CONSTRAINT(DST[4]), CONSTRAINT(DST[5]),    \
+                   CONSTRAINT(DST[6]), CONSTRAINT(DST[7])                                                                                   \
+                 : "v"((uint32_t)(uintptr_t)(ADDR)) : "memory")
+#define RPW_LDS_WAIT8(N, X)                                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]))
     for (;;) {                                             // one slot per iteration
         if (!have) {
             // ---- nothing usable prefetched: wait for a slot (or for the feeder to leave); a pass's layout is read here ----
@@ -1578,12 +1283,10 @@ __device__ __attribute__((noinline)) void srv1_loop(SrvShared* sv, Fit1Shared* s
             // last slot of this one added, and by then this wave has found nothing published and is polling)
             if (cons == start) acc = 0.0f;                         // Zero(), then +=
             src = ringrow + ((cons - start) & nsm) * stride;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const lds_f4*>(src + 4 * q);
+            RPW_LDS_READ8(A, "=v", src, 0);
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) B[q] = *reinterpret_cast<const lds_f4*>(src + 32 + 4 * q);
-        __builtin_amdgcn_sched_barrier(0);
+        RPW_LDS_READ8(B, "=v", src, 128);                          // the slot's second half ...
+        RPW_LDS_WAIT8(8, A);                                       // ... may still be on its way; the first half is there
 #pragma unroll
         for (int q = 0; q < 8; ++q) RPW_CHAIN4(acc, A[q])
         __builtin_amdgcn_sched_barrier(0);
@@ -1594,9 +1297,9 @@ __device__ __attribute__((noinline)) void srv1_loop(SrvShared* sv, Fit1Shared* s
         // to THIS pass (see above), so stride and nsm still hold.
         const uint32_t pubv = *pubw;
         src = ringrow + ((cons - start) & nsm) * stride;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) A[q] = *reinterpret_cast<const lds_f4*>(src + 4 * q);
-        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        RPW_LDS_READ8(A, "+v", src, 0);
+        RPW_LDS_WAIT8(9, B);                                       // behind the second half: the count and the eight reads just issued
 #pragma unroll
         for (int q = 0; q < 8; ++q) RPW_CHAIN4(acc, B[q])
         __builtin_amdgcn_sched_barrier(0);
@@ -1605,9 +1308,11 @@ __device__ __attribute__((noinline)) void srv1_loop(SrvShared* sv, Fit1Shared* s
         *consw = cons;
         have = (int32_t)(uni(pubv) - cons) > 0;                    // else: poll, then read the slot's first half again
     }
+#undef RPW_LDS_READ8
+#undef RPW_LDS_WAIT8
 }
 
-// feeder half of a chain sweep (the server form's w2_sweep_feed): slot s goes to ring slot s % kSrvSweepSlots once the
+// feeder half of a chain sweep: slot s goes to ring slot s % kSrvSweepSlots once the
 // server has added slot s - kSrvSweepSlots
 template <int MODE, int IW>
 __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t count, const SweepPrm& prm, lds_f32* ring, const SrvPort& pt, int lane)
@@ -1768,8 +1473,6 @@ __device__ __forceinline__ void srv_leave(SrvShared* sv, int lane)
     if (lane == 0) atomicAdd(&sv->done, 1u);
 }
 
-// W = 1: one wave per patch (16 patches per CU: the throughput form). W = 2: chain wave + helper wave (8 patches per CU:
-// the latency form, about half the time per patch); the host picks by the number of patches in the launch.
 // work item -> patch, largest size bucket first; false when the launch has fewer patches than that
 __device__ __forceinline__ bool patch_of_item(const DevParams& p, uint32_t item, int lane, uint32_t& linear)
 {
@@ -1784,17 +1487,17 @@ __device__ __forceinline__ bool patch_of_item(const DevParams& p, uint32_t item,
     return true;
 }
 
-// One patch, on the wave that owns it. W = 1: alone; W = 2: with the helper wave of its workgroup; W = 3: as feeder `feeder`
-// of a chain-server workgroup.
+// One patch, on the wave that owns it. W = 1: alone; W = 3: as feeder `feeder` of a chain-server workgroup (a server of
+// seven feeders, or a server of its own).
 template <int W>
 __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, uint32_t linear, int lane, SrvShared* sv, int feeder)
 {
 #define W1_PH(IDX, CNT, ...) { __VA_ARGS__; }
-    // the passes that run a chain: single-wave form, chain half here + feeding half on the helper wave, or feeding half here
-    // + the adds on the server wave
-#define W_SWEEP(ND, M, MODE, INDEXED, PRM) (W == 3 ? srv_chain_sweep(ND, M, MODE, PRM, ring, sv, feeder) : W == 2 ? w2_chain_sweep(&sh, ND, M, MODE, PRM) : w1_chain_sweep(ND, M, MODE, INDEXED, PRM, ring))
-#define W_FUSED(ND, MODE, PRM) (W == 3 ? srv_fused_pass(ND, MODE, PRM, ring, sv, feeder) : W == 2 ? w2_fused_pass(&sh, ND, MODE, PRM) : w1_fused_pass(ND, MODE, PRM, ring))
-#define W_LEAVE() { if (W == 2) { if (lane == 0) sh.cmd[0] = (uint32_t)kCmdExit; w2_barrier(); } }
+    // the passes that run a chain: everything on this wave (single-wave form), or the feeding half here and the adds on a
+    // server wave
+#define W_SWEEP(ND, M, MODE, INDEXED, PRM) (W == 3 ? srv_chain_sweep(ND, M, MODE, PRM, ring, sv, feeder) : w1_chain_sweep(ND, M, MODE, INDEXED, PRM, ring))
+#define W_FUSED(ND, MODE, PRM) (W == 3 ? srv_fused_pass(ND, MODE, PRM, ring, sv, feeder) : w1_fused_pass(ND, MODE, PRM, ring))
+#define W_LEAVE() {}
     const int frame = (int)(linear / (uint32_t)p.P), patch = (int)(linear % (uint32_t)p.P);
     const PatchDesc pd = p.patches[linear];
     const uint32_t fo = p.frame_off[frame];
@@ -2089,18 +1792,15 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
 #undef W_FUSED
 #undef W_LEAVE
 
-template <int W>
-__global__ __launch_bounds__(kFit1Threads * W, 4) void patch_fit1_kernel(DevParams p)
+// The single-wave form: one wave per patch runs everything, the dependent adds included (the form the server forms were
+// derived from; RPW_FIT_WAVES=1 selects it).
+__global__ __launch_bounds__(kFit1Threads, 4) void patch_fit1_kernel(DevParams p)
 {
     __shared__ Fit1Shared sh;
     const int lane = threadIdx.x & 63;
     uint32_t linear;
     if (!patch_of_item(p, blockIdx.x, lane, linear)) return;
-    if (W == 2 && threadIdx.x >= 64) {                 // the helper wave: serves the chain wave until told to leave
-        w2_helper_loop(&sh);
-        return;
-    }
-    fit_patch<W>(p, sh, linear, lane, nullptr, 0);
+    fit_patch<1>(p, sh, linear, lane, nullptr, 0);
 }
 
 // The chain-server form: wave 0 adds, waves 1..kSrvFeeders take patches from the launch's work counter until it runs out.
@@ -2127,8 +1827,8 @@ __global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void patch_fit_srv_ke
 
 // The same division of labour for a launch of FEW patches (one frame, a pipeline slot): one workgroup per patch, wave 0 its
 // server (srv1_loop), wave 1 the feeder that owns the patch. What counts here is the time of the slowest patch, i.e. cycles
-// per addend of one chain: 8.4-8.6 with this server, where a chain wave that meets its helper wave at a barrier per 64
-// addends (patch_fit1_kernel<2>, rounds 2's latency form) needs 10.1-10.9.
+// per addend of one chain: 9.0-9.7 in the sweeps with this server (tools/loop_form_probe.py); round 2's latency form, a chain
+// wave that met a helper wave at a barrier per 64 addends, needed 9.8-10.2 and a protocol of its own (removed).
 __global__ __launch_bounds__(2 * kWave, 4) void patch_fit_srv1_kernel(DevParams p)
 {
     __shared__ SrvShared sv;
@@ -2166,12 +1866,10 @@ __global__ void debug_eig3_kernel(const float* cov, float* nrm, uint32_t n)
 // micro-benchmark of the two loops patch_fit1 lives in (test hook rpw_debug_loop_bench): every block runs `reps`
 // chain sweeps (what = sweep mode) or mask passes (what = 16 + mask mode) over its own synthetic node of n slots
 // ------------------------------------------------------------------------------------------
-template <int W>
-__global__ __launch_bounds__(kFit1Threads * W, 4) void w1_loop_bench_kernel(const float* sx, const float* sy, const float* sz, uint8_t* mask,
+__global__ __launch_bounds__(kFit1Threads, 4) void w1_loop_bench_kernel(const float* sx, const float* sy, const float* sz, uint8_t* mask,
                                                                             uint32_t* il, uint32_t n, uint32_t count, int what, int reps, float* out, unsigned long long* ticks)
 {
     __shared__ Fit1Shared sh;
-    if (W == 2 && threadIdx.x >= 64) { w2_helper_loop(&sh); return; }
     const int lane = threadIdx.x & 63;
     lds_f32* ring = (lds_f32*)sh.ring;
     const size_t base = (size_t)blockIdx.x * n;
@@ -2188,15 +1886,14 @@ __global__ __launch_bounds__(kFit1Threads * W, 4) void w1_loop_bench_kernel(cons
             }
         } else if (what < 16) {
             SweepPrm prm; prm.a = 0.25f + acc * 0.0f; prm.b = -0.5f; prm.c = 0.125f; prm.d = 0.0f; prm.e = 0.0f; prm.f = 1.0f;
-            const Sums6 v = W == 2 ? w2_chain_sweep(&sh, nd, count, what, prm) : w1_chain_sweep(nd, count, what, 1, prm, ring);
+            const Sums6 v = w1_chain_sweep(nd, count, what, 1, prm, ring);
             acc += v.v[0];
         } else {
             MaskPrm mp; mp.cx = 0.0f; mp.cy = 0.0f; mp.cz = acc * 0.0f; mp.nx = 0.0f; mp.ny = 0.0f; mp.nz = 1.0f; mp.thr = 0.6f;
             if (what == 18) { const MaskOut o = w1_mask_pass(nd, kMaskOlder, mp); acc += (float)o.count; }
-            else { const FusedOut o = W == 2 ? w2_fused_pass(&sh, nd, what - 16, mp) : w1_fused_pass(nd, what - 16, mp, ring); acc += (float)o.count + o.sx * 0.0f; }
+            else { const FusedOut o = w1_fused_pass(nd, what - 16, mp, ring); acc += (float)o.count + o.sx * 0.0f; }
         }
     }
-    if (W == 2) { if (lane == 0) sh.cmd[0] = (uint32_t)kCmdExit; w2_barrier(); }
     if (lane == 0) { out[blockIdx.x] = acc; if (blockIdx.x == 0) ticks[0] = __builtin_readcyclecounter() - tick0; }
 }
 
@@ -2369,14 +2066,14 @@ void launch_fit(const DevParams& p, hipStream_t s)
         const size_t per = (160u * 1024u) / (size_t)k, stat = sizeof(Fit1Shared) + 64;
         return per > stat ? ((per - stat) & ~(size_t)255) : (size_t)0;
     }();
-    // RPW_FIT_WAVES=1|2|3|4 forces a form (tests, A/B measurements): one wave per patch, chain + helper wave, chain server,
-    // one server per patch.
+    // RPW_FIT_WAVES=1|3|4 forces a form (tests, A/B measurements): one wave per patch, one chain server for seven patches, one
+    // server per patch.
     static const int forced = [] { const char* e = getenv("RPW_FIT_WAVES"); return e ? atoi(e) : 0; }();
-    if (forced == 1) { hipLaunchKernelGGL(patch_fit1_kernel<1>, dim3(grid), dim3(kFit1Threads), pad, s, p); return; }
-    if (forced == 4) { hipLaunchKernelGGL(patch_fit_srv1_kernel, dim3(grid), dim3(2 * kWave), 0, s, p); return; }
-    // few patches in the launch (a frame or a few: the host-pointer path) -> a chain wave + a helper wave per patch, the form
-    // with the shortest time per patch; a batch -> the chain-server form, the one with the fewest instructions per point
-    if (forced == 2 || (forced == 0 && grid <= 8u * 256u)) { hipLaunchKernelGGL(patch_fit1_kernel<2>, dim3(grid), dim3(2 * kFit1Threads), pad, s, p); return; }
+    if (forced == 1) { hipLaunchKernelGGL(patch_fit1_kernel, dim3(grid), dim3(kFit1Threads), pad, s, p); return; }
+    // few patches in the launch (a frame or a few: the host-pointer path) -> a server wave of its own for every patch, the
+    // form with the shortest time per patch; a batch -> one server for seven patch owners, the form with the fewest
+    // instructions per point
+    if (forced == 4 || (forced == 0 && grid <= 8u * 256u)) { hipLaunchKernelGGL(patch_fit_srv1_kernel, dim3(grid), dim3(2 * kWave), 0, s, p); return; }
     // chain-server form: persistent workgroups (two fit a CU), each feeder pulls patches until the work counter runs out
     allow_srv_lds(reinterpret_cast<const void*>(patch_fit_srv_kernel));
     uint32_t wgs = (grid + (uint32_t)kSrvFeeders - 1u) / (uint32_t)kSrvFeeders;
@@ -2402,7 +2099,7 @@ void launch_frame_copy_out(const uint8_t* labels, uint8_t* h_labels, uint32_t n,
 void launch_loop_bench(const float* sx, const float* sy, const float* sz, uint8_t* mask, uint32_t* il, uint32_t n, uint32_t count,
                        int what, int reps, uint32_t blocks, float* out, unsigned long long* ticks, hipStream_t s)
 {
-    const int w = 1 + (what >> 5);      // what + 32: the same loop in the two-wave form, + 64: chain-server form, + 96: one server per node
+    const int w = 1 + (what >> 5);      // what + 64: the same loop in the chain-server form (seven nodes per server), + 96: one server per node
     what &= 31;
     if (w == 4) { hipLaunchKernelGGL(srv1_loop_bench_kernel, dim3(blocks), dim3(2 * kWave), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out, ticks); return; }
     if (w == 3) {
@@ -2411,8 +2108,7 @@ void launch_loop_bench(const float* sx, const float* sy, const float* sz, uint8_
         hipLaunchKernelGGL(srv_loop_bench_kernel, dim3(wgs), dim3(kWave * (1 + kSrvFeeders)), kSrvLdsBytes, s, sx, sy, sz, mask, il, n, count, what, reps, blocks, out, ticks);
         return;
     }
-    if (w == 2) hipLaunchKernelGGL(w1_loop_bench_kernel<2>, dim3(blocks), dim3(2 * kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out, ticks);
-    else        hipLaunchKernelGGL(w1_loop_bench_kernel<1>, dim3(blocks), dim3(kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out, ticks);
+    hipLaunchKernelGGL(w1_loop_bench_kernel, dim3(blocks), dim3(kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out, ticks);
 }
 void launch_debug_angles(const float* x, const float* y, float* a, uint32_t n, hipStream_t s)
 {

@@ -8,8 +8,8 @@ eng = rpw_amd.Engine(rpw_amd.PatchworkConfig(), max_points=1024, max_frames=1)
 names = {0: "sweep xyz (3 rows)", 1: "sweep cov (6 rows)", 2: "sweep |d| (1 row)", 3: "sweep range (1 row, all slots)",
          17: "fused pass plane (mask + centroid chain)", 16: "fused pass seed (mask + centroid chain)"}
 pct = 56
-FORM = {1: "one wave per node", 2: "chain wave + helper wave per node", 3: "chain-server form (7 nodes per workgroup of 8 waves)"}
-for blocks, waves in ((1, 1), (1, 2), (1, 3), (7, 3), (256 * 4, 1), (256 * 4, 2), (256 * 7, 3), (256 * 16, 1), (256 * 8, 2), (256 * 14, 3), (256 * 28, 3)):
+FORM = {1: "one wave per node", 3: "chain-server form (7 nodes per workgroup of 8 waves)", 4: "one server wave per node"}
+for blocks, waves in ((1, 1), (1, 4), (1, 3), (7, 3), (256 * 4, 1), (256 * 4, 4), (256 * 7, 3), (256 * 16, 1), (256 * 8, 4), (256 * 14, 3), (256 * 28, 3)):
     print(f"--- {blocks} nodes ({blocks / 256:.1f} per CU), {FORM[waves]}, node of {n} slots, {pct} % inliers")
     for what, nm in names.items():
         reps = 20

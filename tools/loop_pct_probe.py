@@ -6,8 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rpw_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 eng = rpw_amd.Engine(rpw_amd.PatchworkConfig(), max_points=1024, max_frames=1)
-FORM = {1: "one wave", 2: "chain + helper wave", 3: "chain server (lone feeder)", 4: "one server per node"}
-for waves in (1, 2, 3, 4):
+FORM = {1: "one wave", 3: "chain server (lone feeder)", 4: "one server per node"}
+for waves in (1, 3, 4):
     for what, nm in ((17, "fused pass (plane)"), (1, "covariance sweep")):
         row = []
         for pct in (5, 20, 40, 56, 80, 100):
