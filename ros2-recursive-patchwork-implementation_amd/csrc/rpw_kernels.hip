@@ -719,7 +719,6 @@ template <int MODE, int IW, class CH>
 __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskPrm& prm, lds_f32* ring, int lane, CH& ch)
 {
     typedef __attribute__((address_space(1))) char g_char;
-    typedef float v4f __attribute__((ext_vector_type(4)));
     g_char* il = reinterpret_cast<g_char*>(nd.il);
     const uint32_t n = nd.n;
     const uint32_t nfull = n / kWave;
