@@ -34,6 +34,8 @@ cp "$(find "$OUT/stats_c5" -name '*kernel_stats.csv' | head -1)" "$OUT/export/${
 python3 tools/trace_phase_avg.py "$(find "$OUT/stats_bench" -name '*kernel_trace.csv' | head -1)" 7 56 > "$OUT/export/${R}_bench_kernel_trace_summary.json"
 # 5. the loop micro-benchmark and the host path probe
 python3 tools/loop_bench.py 8192 > "$OUT/export/${R}_loop_bench.txt" 2>/dev/null
+python3 tools/loop_form_probe.py 8192 > "$OUT/export/${R}_loop_form_probe.txt" 2>/dev/null
+python3 tools/loop_pct_probe.py 8192 > "$OUT/export/${R}_loop_pct_probe.txt" 2>/dev/null
 python3 tools/host_path_probe.py --slots 1,2,4,8,16 > "$OUT/export/${R}_host_path_probe.json" 2>/dev/null
 ls "$OUT/export"
 tail -c 400 "$OUT/export/${R}_bench_default.json"
