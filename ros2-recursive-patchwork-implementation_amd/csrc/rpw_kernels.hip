@@ -842,7 +842,7 @@ template <int MODE> struct SweepRows { static constexpr int K = MODE == kSweepCo
 //   steps 0-7  (first half of slot t, second half's reads)   : addends of slot t + 1 -> ring
 //   steps 8-15 (second half of slot t, reads of slot t + 1)   : point loads of slot t + 4, index load of slot t + 6
 template <int MODE, int IW>        // IW: bytes per index list entry, 0 = the sweep runs over every slot of the node
-__device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count, const SweepPrm& prm, lds_f32* ring, int lane)
+__device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count, const SweepPrm& prm, lds_f32* ring, int lane, float& zmn, float& zmx)
 {
     constexpr int K = SweepRows<MODE>::K;
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -859,7 +859,7 @@ __device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count
     };
     auto point_of = [&](uint32_t idx) -> X3 {
         X3 q; q.x = ldg_f32(nd.x, idx); q.y = ldg_f32(nd.y, idx);
-        q.z = (MODE == kSweepXYZ || MODE == kSweepCov || MODE == kSweepDist) ? ldg_f32(nd.z, idx) : 0.0f;
+        q.z = (MODE == kSweepXYZ || MODE == kSweepCov || MODE == kSweepDist || MODE == kSweepRange) ? ldg_f32(nd.z, idx) : 0.0f;
         return q;
     };
     // addends of one element, in two halves (so that they can sit in two different steps)
@@ -875,7 +875,7 @@ __device__ __forceinline__ float w1_sweep_loop(const NodeRef& nd, uint32_t count
             v[0] = a.x; v[1] = a.y;                         // (0,0) (1,0)
         } else if (MODE == kSweepXYZ) { v[0] = q.x; v[1] = q.y; v[2] = q.z; }
         else if (MODE == kSweepDist)  { v[0] = plane_dist(q.x, q.y, q.z, prm.a, prm.b, prm.c, prm.d, prm.e, prm.f); }
-        else if (MODE == kSweepRange) { v[0] = sqrt_rn(q.x * q.x + q.y * q.y); }
+        else if (MODE == kSweepRange) { v[0] = sqrt_rn(q.x * q.x + q.y * q.y); zmn = fminf(zmn, q.z); zmx = fmaxf(zmx, q.z); }      // (+ the node's z range: order-free)
         else if (MODE == kSweepXY)    { v[0] = q.x; v[1] = q.y; }
         else { const float dx = q.x - prm.a, dy = q.y - prm.b; v[0] = dx * dx; v[1] = dy * dy; }
     };
@@ -971,19 +971,22 @@ __device__ __attribute__((noinline)) Sums6 w1_chain_sweep(NodeRef nd_in, uint32_
     for (int k = 0; k < 6; ++k) out.v[k] = 0.0f;
     if (count == 0) return out;
     float acc;
+    float zmn = 3.402823466e+38f, zmx = -3.402823466e+38f;      // kSweepRange also returns the z range of the elements (v[1], v[2])
     // (mode and indexed arrive in vector registers; the wave-uniform copy makes these scalar branches)
     const bool narrow = nd.n <= 65536u;                // the width the pass that wrote the list used
-    switch (__builtin_amdgcn_readfirstlane(mode)) {
-    case kSweepCov:   acc = narrow ? w1_sweep_loop<kSweepCov, 2>(nd, count, prm, ring, lane) : w1_sweep_loop<kSweepCov, 4>(nd, count, prm, ring, lane); break;
-    case kSweepXYZ:   acc = narrow ? w1_sweep_loop<kSweepXYZ, 2>(nd, count, prm, ring, lane) : w1_sweep_loop<kSweepXYZ, 4>(nd, count, prm, ring, lane); break;
-    case kSweepDist:  acc = narrow ? w1_sweep_loop<kSweepDist, 2>(nd, count, prm, ring, lane) : w1_sweep_loop<kSweepDist, 4>(nd, count, prm, ring, lane); break;
-    case kSweepRange: acc = w1_sweep_loop<kSweepRange, 0>(nd, count, prm, ring, lane); break;
-    case kSweepXY:    acc = w1_sweep_loop<kSweepXY, 0>(nd, count, prm, ring, lane); break;
-    default:          acc = w1_sweep_loop<kSweepVarXY, 0>(nd, count, prm, ring, lane); break;
+    const int m = __builtin_amdgcn_readfirstlane(mode);
+    switch (m) {
+    case kSweepCov:   acc = narrow ? w1_sweep_loop<kSweepCov, 2>(nd, count, prm, ring, lane, zmn, zmx) : w1_sweep_loop<kSweepCov, 4>(nd, count, prm, ring, lane, zmn, zmx); break;
+    case kSweepXYZ:   acc = narrow ? w1_sweep_loop<kSweepXYZ, 2>(nd, count, prm, ring, lane, zmn, zmx) : w1_sweep_loop<kSweepXYZ, 4>(nd, count, prm, ring, lane, zmn, zmx); break;
+    case kSweepDist:  acc = narrow ? w1_sweep_loop<kSweepDist, 2>(nd, count, prm, ring, lane, zmn, zmx) : w1_sweep_loop<kSweepDist, 4>(nd, count, prm, ring, lane, zmn, zmx); break;
+    case kSweepRange: acc = w1_sweep_loop<kSweepRange, 0>(nd, count, prm, ring, lane, zmn, zmx); break;
+    case kSweepXY:    acc = w1_sweep_loop<kSweepXY, 0>(nd, count, prm, ring, lane, zmn, zmx); break;
+    default:          acc = w1_sweep_loop<kSweepVarXY, 0>(nd, count, prm, ring, lane, zmn, zmx); break;
     }
     (void)indexed;
 #pragma unroll
     for (int k = 0; k < 6; ++k) out.v[k] = __shfl(acc, k);
+    if (m == kSweepRange) { out.v[1] = wave_min(zmn); out.v[2] = wave_max(zmx); }
     return out;
 }
 
@@ -1332,7 +1335,7 @@ __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t coun
     };
     auto point_of = [&](uint32_t idx) -> X3 {
         X3 q; q.x = ldg_f32(nd.x, idx); q.y = ldg_f32(nd.y, idx);
-        q.z = (MODE == kSweepXYZ || MODE == kSweepCov || MODE == kSweepDist) ? ldg_f32(nd.z, idx) : 0.0f;
+        q.z = (MODE == kSweepXYZ || MODE == kSweepCov || MODE == kSweepDist || MODE == kSweepRange) ? ldg_f32(nd.z, idx) : 0.0f;
         return q;
     };
     const uint32_t start = srv_begin(pt, srv_layout((uint32_t)kSlotFloats, (uint32_t)kSrvSweepSlots), (uint32_t)K, lane);
@@ -1344,6 +1347,7 @@ __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t coun
     // deep (that was the case here until round 3; at full occupancy the covariance sweep ran 20 % slower for it).
     constexpr int D = kSrvSweepDepth;
     X3 P[D]; uint32_t I[D];
+    float zmn = 3.402823466e+38f, zmx = -3.402823466e+38f;      // kSweepRange also returns the z range of the elements (v[1], v[2])
 #pragma unroll
     for (int k = 0; k < D; ++k) I[k] = index_of((uint32_t)k);
 #pragma unroll
@@ -1362,7 +1366,7 @@ __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t coun
             v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
         } else if (MODE == kSweepXYZ) { v[0] = q.x; v[1] = q.y; v[2] = q.z; }
         else if (MODE == kSweepDist)  { v[0] = plane_dist(q.x, q.y, q.z, prm.a, prm.b, prm.c, prm.d, prm.e, prm.f); }
-        else if (MODE == kSweepRange) { v[0] = sqrt_rn(q.x * q.x + q.y * q.y); }
+        else if (MODE == kSweepRange) { v[0] = sqrt_rn(q.x * q.x + q.y * q.y); zmn = fminf(zmn, q.z); zmx = fmaxf(zmx, q.z); }      // (+ the node's z range: order-free)
         else if (MODE == kSweepXY)    { v[0] = q.x; v[1] = q.y; }
         else { const float dx = q.x - prm.a, dy = q.y - prm.b; v[0] = dx * dx; v[1] = dy * dy; }
         if (s >= (uint32_t)kSrvSweepSlots) srv_wait(pt, start + s - (uint32_t)(kSrvSweepSlots - 1), seen);
@@ -1385,6 +1389,7 @@ __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t coun
     Sums6 out;
 #pragma unroll
     for (int k = 0; k < 6; ++k) out.v[k] = k < K ? *(volatile lds_f32*)(pt.accp + k) : 0.0f;
+    if (MODE == kSweepRange) { out.v[1] = wave_min(zmn); out.v[2] = wave_max(zmx); }
     return out;
 }
 
@@ -1529,7 +1534,7 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
     lds_f32* ring = (lds_f32*)sh.ring;            // address-space cast: the passes take the ring as an LDS pointer (ds_ instructions, not flat)
     const SweepPrm no_prm = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     // ---- mean distance of the patch (recursive_patchwork.cpp:383-387): sequential sum of d ------
-    float mean_dist;
+    float mean_dist, root_zmn, root_zmx;
     {
         NodeRef root; root.x = (g_cf32*)(p.sx + cx.base); root.y = (g_cf32*)(p.sy + cx.base); root.z = (g_cf32*)(p.sz + cx.base);
         root.m = (g_u8*)(p.mask + cx.base); root.il = (g_u32*)(cx.il + cx.base); root.n = pd.n;
@@ -1537,6 +1542,7 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
         W1_PH(1, pd.n, sum = W_SWEEP(root, pd.n, kSweepRange, 0, no_prm))
         cx.addends += pd.n;
         mean_dist = sum.v[0] / (float)pd.n;
+        root_zmn = sum.v[1]; root_zmx = sum.v[2];      // the patch's z range rides on the same sweep (what the root node's flat test needs)
     }
     const float rel_dist = mean_dist / cfg.filtering_radius;
     const float threshold = cfg.th_dist * (1.0f + 0.2f * rel_dist);
@@ -1568,7 +1574,9 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
         if (n < 3 || depth > cfg.max_split_depth) leaf_kind = RPW_NODE_REJECT;
         if (leaf_kind < 0) {
             float xmn = 3.402823466e+38f, xmx = -3.402823466e+38f, ymn = xmn, ymx = xmx, zmn = xmn, zmx = xmx;
-            {
+            if (depth == 0) {                         // the root: its area is never tested (recursive_patchwork.cpp:127), its z range is known
+                xmn = xmx = ymn = ymx = 0.0f; zmn = root_zmn; zmx = root_zmx;
+            } else {
                 for (uint32_t i0 = lane; i0 < n; i0 += 4 * kFit1Threads) {
                     float x[4], y[4], z[4];
 #pragma unroll
