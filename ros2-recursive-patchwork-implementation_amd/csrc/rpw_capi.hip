@@ -48,7 +48,8 @@ struct Workspace {
     uint32_t* d_bucket_list = nullptr;
     float *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr, *d_ax = nullptr, *d_ay = nullptr, *d_az = nullptr;
     uint32_t* d_sidx = nullptr;
-    uint8_t* d_mask = nullptr;
+    unsigned long long* d_mbits = nullptr;   // three mask bit planes
+    uint32_t mplane = 0;                    // words per plane
     rpw_frame_stats* d_stats = nullptr;
 
     // the batch in flight on this workspace: its stream, its size, and an event recorded behind its last kernel
@@ -132,7 +133,7 @@ void free_workspace(Workspace& w)
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(w.d_offsets); F(w.d_hist); F(w.d_patch_begin); F(w.d_patches);
     F(w.d_ctrl); F(w.d_bucket_list); F(w.d_sx); F(w.d_sy); F(w.d_sz); F(w.d_ax); F(w.d_ay); F(w.d_az);
-    F(w.d_sidx); F(w.d_mask); F(w.d_stats);
+    F(w.d_sidx); F(w.d_mbits); F(w.d_stats);
     for (int i = 0; i < kStageSlots; ++i) {
         if (w.h_offsets[i]) { (void)hipHostFree(w.h_offsets[i]); w.h_offsets[i] = nullptr; }
         if (w.stage_ev[i]) { (void)hipEventDestroy(w.stage_ev[i]); w.stage_ev[i] = nullptr; }
@@ -248,7 +249,8 @@ rpw_status alloc_workspace(rpw_handle* h, Workspace& w, size_t N, size_t F)
     RPW_HIP(h, hipMalloc(&w.d_ay, N * sizeof(float)));
     RPW_HIP(h, hipMalloc(&w.d_az, N * sizeof(float)));
     RPW_HIP(h, hipMalloc(&w.d_sidx, N * sizeof(uint32_t)));
-    RPW_HIP(h, hipMalloc(&w.d_mask, N));
+    w.mplane = (uint32_t)(N / 64 + F * (size_t)h->P + 8);      // a patch starts at word (begin >> 6) + its index in the batch
+    RPW_HIP(h, hipMalloc(&w.d_mbits, 3 * (size_t)w.mplane * sizeof(unsigned long long)));
     RPW_HIP(h, hipMalloc(&w.d_stats, F * sizeof(rpw_frame_stats)));
     return RPW_OK;
 }
@@ -342,7 +344,7 @@ void fill_params(rpw_handle* h, Workspace& w, DevParams& p, const void* d_xyz, u
     p.hist = w.d_hist; p.ftot = w.d_ctrl + kBuckets + 4; p.patch_begin = w.d_patch_begin; p.patches = w.d_patches;
     p.bucket_count = w.d_ctrl; p.bucket_list = w.d_bucket_list; p.list_stride = w.max_frames * (uint32_t)h->P;
     p.sx = w.d_sx; p.sy = w.d_sy; p.sz = w.d_sz; p.sidx = w.d_sidx; p.ax = w.d_ax; p.ay = w.d_ay; p.az = w.d_az;
-    p.mask = w.d_mask; p.stats = w.d_stats;
+    p.mbits = w.d_mbits; p.mplane = w.mplane; p.stats = w.d_stats;
     { static const int remap = [] { const char* e = getenv("RPW_BIN_REMAP"); return e ? atoi(e) : 1; }(); p.bin_remap = remap; }
     // the trace buffer belongs to the handle: only its own workspace writes it
     const bool tracing = (&w == &h->ws) && h->trace && h->d_nodes;
@@ -930,14 +932,21 @@ rpw_status rpw_debug_loop_bench_ticks(rpw_handle* h, int what, uint32_t n, uint3
         if (in) il[count++] = i;
     }
     if (count == 0) { il[0] = 0; count = 1; }
-    float *dx = nullptr, *dy = nullptr, *dz = nullptr, *dout = nullptr; uint8_t* dm = nullptr; uint32_t* dil = nullptr;
+    float *dx = nullptr, *dy = nullptr, *dz = nullptr, *dout = nullptr; unsigned long long* dm = nullptr; uint32_t* dil = nullptr;
+    // mask bit planes: node b starts at word (b * n >> 6) + b of every plane; all three planes hold the synthetic mask
+    const uint32_t mplane = (uint32_t)(total / 64 + blocks + 8);
+    std::vector<unsigned long long> words((size_t)mplane, 0ull);
+    for (uint32_t b = 0; b < blocks; ++b) {
+        const size_t w0 = (((size_t)b * n) >> 6) + b;
+        for (uint32_t i = 0; i < n; ++i) if (m[i]) words[w0 + (i >> 6)] |= 1ull << (i & 63u);
+    }
     auto cleanup = [&]() { (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dz); (void)hipFree(dout); (void)hipFree(dm); (void)hipFree(dil); };
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMalloc(&dx, total * 4);
     if (e == hipSuccess) e = hipMalloc(&dy, total * 4);
     if (e == hipSuccess) e = hipMalloc(&dz, total * 4);
     if (e == hipSuccess) e = hipMalloc(&dil, total * 4);
-    if (e == hipSuccess) e = hipMalloc(&dm, total);
+    if (e == hipSuccess) e = hipMalloc(&dm, 3 * (size_t)mplane * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&dout, (size_t)blocks * 4);
     unsigned long long* dticks = nullptr;
     if (e == hipSuccess) e = hipMalloc(&dticks, 8);
@@ -946,17 +955,17 @@ rpw_status rpw_debug_loop_bench_ticks(rpw_handle* h, int what, uint32_t n, uint3
         if (e == hipSuccess) e = hipMemcpy(dy + (size_t)b * n, y.data(), (size_t)n * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(dz + (size_t)b * n, z.data(), (size_t)n * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(dil + (size_t)b * n, il.data(), (size_t)n * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dm + (size_t)b * n, m.data(), (size_t)n, hipMemcpyHostToDevice);
     }
+    for (int k = 0; e == hipSuccess && k < 3; ++k) e = hipMemcpy(dm + (size_t)k * mplane, words.data(), (size_t)mplane * sizeof(unsigned long long), hipMemcpyHostToDevice);
     hipEvent_t ea = nullptr, eb = nullptr;
     if (e == hipSuccess) e = hipEventCreate(&ea);
     if (e == hipSuccess) e = hipEventCreate(&eb);
     float t = 0.0f;
     if (e == hipSuccess) {
         const uint32_t cnt = base_what < 16 ? (base_what == kSweepRangeMode || base_what >= 4 ? n : count) : n;
-        launch_loop_bench(dx, dy, dz, dm, dil, n, cnt, what, 1, blocks, dout, dticks, nullptr);            // warm-up
+        launch_loop_bench(dx, dy, dz, dm, mplane, dil, n, cnt, what, 1, blocks, dout, dticks, nullptr);            // warm-up
         e = hipEventRecord(ea, nullptr);
-        launch_loop_bench(dx, dy, dz, dm, dil, n, cnt, what, reps, blocks, dout, dticks, nullptr);
+        launch_loop_bench(dx, dy, dz, dm, mplane, dil, n, cnt, what, reps, blocks, dout, dticks, nullptr);
         if (e == hipSuccess) e = hipEventRecord(eb, nullptr);
         if (e == hipSuccess) e = hipEventSynchronize(eb);
         if (e == hipSuccess) e = hipEventElapsedTime(&t, ea, eb);

@@ -68,7 +68,8 @@ struct DevParams {
     float *sx, *sy, *sz;          // patch-sorted SoA, input order inside a patch (written by bin_tile's scatter pass)
     uint32_t* sidx;               // original index inside the frame, per slot (never permuted)
     float *ax, *ay, *az;          // scratch for the stable partition
-    uint8_t* mask;                // per slot: bit0 = current inlier mask, bit1 = previous mask
+    unsigned long long* mbits;    // inlier masks as bit planes: three planes of `mplane` words, one word per chunk of 64 node slots
+    uint32_t mplane;              // (patch p of the batch starts at word (begin >> 6) + p of every plane)
 
     rpw_frame_stats* stats;       // [F]
     rpw_node* nodes;              // trace (may be null)
@@ -86,7 +87,7 @@ void launch_fit(const DevParams& p, hipStream_t s);
 void launch_frame_setup(uint32_t* offsets, uint32_t n, uint32_t tiles, uint32_t* ctrl, uint32_t ctrl_words, hipStream_t s);
 void launch_frame_copy_out(const uint8_t* labels, uint8_t* h_labels, uint32_t n, const float* res, float* h_res,
                            const rpw_frame_stats* stats, rpw_frame_stats* h_stats, const uint32_t* fit_error, hipStream_t s);
-void launch_loop_bench(const float* sx, const float* sy, const float* sz, uint8_t* mask, uint32_t* il, uint32_t n, uint32_t count,
+void launch_loop_bench(const float* sx, const float* sy, const float* sz, unsigned long long* mw, uint32_t mplane, uint32_t* il, uint32_t n, uint32_t count,
                        int what, int reps, uint32_t blocks, float* out, unsigned long long* ticks, hipStream_t s);
 void launch_result_record(const rpw_frame_stats* stats, int32_t* out, uint32_t n_frames, const uint32_t* fit_error, hipStream_t s);
 void launch_debug_angles(const float* x, const float* y, float* a, uint32_t n, hipStream_t s);

@@ -476,14 +476,13 @@ static_assert(kW1Ring * kSlotFloats <= kRingFloats, "the sweep ring must fit");
 struct W1 {
     const float *sx, *sy, *sz;         // patch-sorted SoA
     uint32_t* il;                      // inlier index list of the current node (node-relative slot numbers, ascending)
-    uint8_t* mask;
     Fit1Shared* sh;
     uint32_t base;                     // absolute slot of the patch's first point
     int lane;
     unsigned long long addends;        // chain steps so far (statistics)
 };
 
-struct P4 { float x, y, z; uint32_t m; };
+struct P4 { float x, y, z; };
 
 // Ordering INSIDE one wave (a lane reads what another lane of the same wave wrote, in LDS or in global memory through the
 // CU's L1): earlier accesses complete before later ones start. No s_barrier: the waves of a workgroup run independent
@@ -498,11 +497,15 @@ typedef __attribute__((address_space(3))) uint32_t lds_word;
 // (explicit global address space: a plain pointer that arrives as a function argument is "generic", and generic
 // accesses compile to flat_ instructions that count against the LDS counter as well)
 typedef __attribute__((address_space(1))) const float g_cf32;
-typedef __attribute__((address_space(1))) uint8_t g_u8;
 typedef __attribute__((address_space(1))) uint32_t g_u32;
+typedef __attribute__((address_space(1))) unsigned long long g_u64;
+// Inlier masks are BIT PLANES: one 64-bit word per chunk of 64 node slots (bit l = slot 64 c + l), three planes that rotate
+// -- a pass reads the current mask and the one before it (two words per chunk) and writes the new one into the third. The masks
+// are temporaries of the node being fitted, so every node of a patch uses the patch's words from their start.
+// (Rounds 1-2 kept a history BYTE per slot: 1 B read + 1 B written per slot and refit, where this is 0.375 B.)
 struct NodeRef {
     g_cf32 *x, *y, *z;                 // patch-sorted SoA, at the node's first slot
-    g_u8* m;                           // mask history bytes
+    g_u64 *mnew, *mcur, *mprev;        // mask planes: written by the pass / the current mask / the mask before it
     g_u32* il;                         // inlier index list (node-relative slot numbers, ascending)
     uint32_t n;                        // slots in the node
 };
@@ -523,7 +526,8 @@ template <class T> __device__ __forceinline__ T* uni_ptr(T* p)
 }
 __device__ __forceinline__ NodeRef uni(NodeRef nd)
 {
-    nd.x = uni_ptr(nd.x); nd.y = uni_ptr(nd.y); nd.z = uni_ptr(nd.z); nd.m = uni_ptr(nd.m); nd.il = uni_ptr(nd.il); nd.n = uni(nd.n);
+    nd.x = uni_ptr(nd.x); nd.y = uni_ptr(nd.y); nd.z = uni_ptr(nd.z); nd.mnew = uni_ptr(nd.mnew); nd.mcur = uni_ptr(nd.mcur); nd.mprev = uni_ptr(nd.mprev);
+    nd.il = uni_ptr(nd.il); nd.n = uni(nd.n);
     return nd;
 }
 
@@ -532,19 +536,20 @@ __device__ __forceinline__ P4 w1_load(const NodeRef& nd, uint32_t i)
 {
     P4 r;
     r.x = ldg_f32(nd.x, i); r.y = ldg_f32(nd.y, i); r.z = ldg_f32(nd.z, i);
-    r.m = (uint32_t)nd.m[i];
     return r;
 }
+// word c of a mask plane, the same for every lane (one request; the value is wave-uniform)
+__device__ __forceinline__ unsigned long long mask_word(g_u64* plane, uint32_t c)
+{
+    const unsigned long long w = plane[c];
+    return ((unsigned long long)uni((uint32_t)(w >> 32)) << 32) | (unsigned long long)uni((uint32_t)w);
+}
 
-// MASK PASS over the node: evaluates the inlier predicate of every slot, keeps the mask history byte, and writes the
-// inliers' slot numbers to the index list in slot order.
-//   kMaskSeed   inlier = z < prm.thr                      byte := inlier
-//   kMaskPlane  inlier = |(p - c) . n| < prm.thr          byte := inlier | history << 1; flags: changed / differs from the mask before
-//   kMaskOlder  inlier = bit 1 of the byte (the mask one iteration back); the byte is left alone
-// The list has one entry per slot of the node: inliers fill it from the front in slot order, the others fill it from the
-// back -- so every lane stores exactly one entry per chunk and the loop over the full chunks is ONE basic block (a
-// conditional store is a branch around it, and a loop with branches gets a full s_waitcnt vmcnt(0) at its head: the
-// four-chunk prefetch then hides nothing). Only the last, partial chunk is handled with conditions.
+// MASK PASS over the node, kMaskOlder: the index list of the mask one iteration back (plane `mprev`), inliers in slot order --
+// for the residual of a period-2 fit that ends on the older mask. (The seed and plane predicates run in the fused pass below.)
+//   kMaskSeed   inlier = z < prm.thr
+//   kMaskPlane  inlier = |(p - c) . n| < prm.thr          flags: changed / differs from the mask before
+//   kMaskOlder  inlier = the bit of the mask one iteration back
 enum { kMaskSeed = 0, kMaskPlane = 1, kMaskOlder = 2 };
 struct MaskPrm { float cx, cy, cz, nx, ny, nz, thr; };
 struct MaskOut { uint32_t count, changed, differs_prev; };
@@ -564,75 +569,22 @@ template <int IW> __device__ __forceinline__ uint32_t il_load(__attribute__((add
     return *reinterpret_cast<const g_u32*>(il + pos * 4u);
 }
 
-// Plain mask pass (no chain): only kMaskOlder uses it in the kernel -- the list of the mask one iteration back, for the
-// residual of a period-2 fit that ends on the older mask. Inliers fill the list from the front in slot order; every
-// other lane stores into the list's LAST entry, which no reader ever reaches when the node has a non-inlier (and when
-// it has none, nobody stores there): every lane stores exactly once per chunk and the loop over the full chunks stays ONE
-// basic block (a conditional store is a branch around it, and a loop with branches gets a full s_waitcnt vmcnt(0) at its
-// head: the four-chunk prefetch then hides nothing). Only the last, partial chunk is handled with conditions.
-template <int MODE, int IW>
-__device__ __forceinline__ MaskOut w1_mask_loop(const NodeRef& nd, const MaskPrm& prm, int lane)
+template <int IW>
+__device__ __forceinline__ MaskOut w1_older_list(const NodeRef& nd, int lane)
 {
     typedef __attribute__((address_space(1))) char g_char;
     g_char* il = reinterpret_cast<g_char*>(nd.il);
-    const uint32_t n = nd.n;
-    const uint32_t nfull = n / kWave;                              // chunks with all 64 slots
-    uint32_t cursor = 0;                                           // inliers so far
-    bool changed = false, differs_prev = false;
-    // one chunk: predicate, history byte, list entry. FULL: all 64 lanes hold a slot.
-    auto step = [&](const P4& r, uint32_t c, auto full) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full)::value;
+    const uint32_t n = nd.n, nchunks = (n + kWave - 1) / kWave;
+    uint32_t cursor = 0;
+    for (uint32_t c = 0; c < nchunks; ++c) {
         const uint32_t i = c * kWave + lane;
-        const bool ok = FULL || i < n;
-        bool in;
-        if (MODE == kMaskPlane) {
-            const float d = plane_dist(r.x, r.y, r.z, prm.cx, prm.cy, prm.cz, prm.nx, prm.ny, prm.nz);
-            in = d < prm.thr;
-            const bool old = r.m & 1u, prev = (r.m >> 1) & 1u;
-            changed |= ok && (in != old);
-            differs_prev |= ok && (in != prev);
-            const uint8_t nb = (uint8_t)((in ? 1u : 0u) | ((r.m & 0x7fu) << 1));
-            if (FULL) nd.m[i] = nb; else if (ok) nd.m[i] = nb;
-        } else if (MODE == kMaskSeed) {
-            in = r.z < prm.thr;
-            if (FULL) nd.m[i] = in ? 1 : 0; else if (ok) nd.m[i] = in ? 1 : 0;
-        } else {
-            in = (r.m >> 1) & 1u;
-        }
-        in = in && ok;
-        const unsigned long long m = ballot64(in);
-        const uint32_t pos = in ? cursor + (uint32_t)mbcnt64(m) : n - 1u;
-        if (FULL) il_store<IW>(il, pos, i);
-        else if (ok) il_store<IW>(il, pos, i);
+        unsigned long long m = mask_word(nd.mprev, c);
+        if ((c + 1u) * kWave > n) m &= (1ull << (n & 63u)) - 1ull;      // the partial chunk: bits past the node are not slots
+        const bool in = (m >> lane) & 1ull;
+        if (in) il_store<IW>(il, cursor + (uint32_t)mbcnt64(m), i);
         cursor += (uint32_t)__popcll(m);
-    };
-    // full chunks, four register sets, each reloaded right after use; chunks past the last full one are not loaded
-    uint32_t c = 0;
-    if (nfull >= 4) {
-        P4 r0 = w1_load(nd, 0 * kWave + lane), r1 = w1_load(nd, 1 * kWave + lane), r2 = w1_load(nd, 2 * kWave + lane), r3 = w1_load(nd, 3 * kWave + lane);
-        const uint32_t lastfull = (nfull - 1u) * kWave;
-        for (; c + 4 <= nfull; c += 4) {
-            // (the reloads clamp to the last full chunk: loads past it would be wasted, never wrong)
-            const uint32_t b4 = (c + 4) * kWave, b5 = b4 + kWave, b6 = b5 + kWave, b7 = b6 + kWave;
-            step(r0, c, yes());     r0 = w1_load(nd, (b4 < lastfull ? b4 : lastfull) + lane);
-            step(r1, c + 1, yes()); r1 = w1_load(nd, (b5 < lastfull ? b5 : lastfull) + lane);
-            step(r2, c + 2, yes()); r2 = w1_load(nd, (b6 < lastfull ? b6 : lastfull) + lane);
-            step(r3, c + 3, yes()); r3 = w1_load(nd, (b7 < lastfull ? b7 : lastfull) + lane);
-        }
     }
-    for (; c < nfull; ++c) {                                       // up to three full chunks left
-        const P4 r = w1_load(nd, c * kWave + lane);
-        step(r, c, yes());
-    }
-    if (nfull * kWave < n) {                                       // the partial chunk
-        const uint32_t i = nfull * kWave + lane;
-        const P4 r = w1_load(nd, i < n ? i : n - 1u);
-        step(r, nfull, no());
-    }
-    MaskOut o;
-    o.count = cursor;
-    o.changed = ballot64(changed) != 0ull ? 1u : 0u;
-    o.differs_prev = ballot64(differs_prev) != 0ull ? 1u : 0u;
+    MaskOut o; o.count = cursor; o.changed = 0u; o.differs_prev = 0u;
     return o;
 }
 
@@ -640,11 +592,9 @@ __device__ __attribute__((noinline)) MaskOut w1_mask_pass(NodeRef nd_in, int mod
 {
     const int lane = threadIdx.x & 63;
     const NodeRef nd = uni(nd_in);
-    prm.cx = uni(prm.cx); prm.cy = uni(prm.cy); prm.cz = uni(prm.cz); prm.nx = uni(prm.nx); prm.ny = uni(prm.ny); prm.nz = uni(prm.nz);
-    prm.thr = uni(prm.thr);
-    (void)mode;
-    if (nd.n <= 65536u) return w1_mask_loop<kMaskOlder, 2>(nd, prm, lane);
-    return w1_mask_loop<kMaskOlder, 4>(nd, prm, lane);
+    (void)mode; (void)prm;
+    if (nd.n <= 65536u) return w1_older_list<2>(nd, lane);
+    return w1_older_list<4>(nd, lane);
 }
 
 // FUSED PASS = mask pass + centroid chain. The inliers of the NEW mask are found chunk by chunk, and their x, y, z go
@@ -723,10 +673,12 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
     const uint32_t n = nd.n;
     const uint32_t nfull = n / kWave;
     uint32_t cursor = 0;                                           // inliers so far = addends written
-    bool changed = false, differs_prev = false;
+    bool changed = false, differs_prev = false;                    // wave-uniform: whole mask words are compared
     const int row = lane < 3 ? lane : 2;
     const lds_f32* rowp = ring + row * kLdw;
-    auto step = [&](const P4& r, uint32_t c, auto full) __attribute__((always_inline)) {
+    // one chunk: predicate -> the new mask word (a ballot), compared as a whole with the chunk's word of the current mask
+    // (wc) and of the mask before it (wp); list entries and centroid addends of the inliers
+    auto step = [&](const P4& r, uint32_t c, unsigned long long wc, unsigned long long wp, auto full) __attribute__((always_inline)) -> unsigned long long {
         constexpr bool FULL = decltype(full)::value;
         const uint32_t i = c * kWave + lane;
         const bool ok = FULL || i < n;
@@ -734,17 +686,16 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
         if (MODE == kMaskPlane) {
             const float d = plane_dist(r.x, r.y, r.z, prm.cx, prm.cy, prm.cz, prm.nx, prm.ny, prm.nz);
             in = d < prm.thr;
-            const bool old = r.m & 1u, prev = (r.m >> 1) & 1u;
-            changed |= ok && (in != old);
-            differs_prev |= ok && (in != prev);
-            const uint8_t nb = (uint8_t)((in ? 1u : 0u) | ((r.m & 0x7fu) << 1));
-            if (FULL) nd.m[i] = nb; else if (ok) nd.m[i] = nb;
         } else {
             in = r.z < prm.thr;
-            if (FULL) nd.m[i] = in ? 1 : 0; else if (ok) nd.m[i] = in ? 1 : 0;
         }
         in = in && ok;
         const unsigned long long m = ballot64(in);
+        if (MODE == kMaskPlane) {
+            const unsigned long long valid = FULL ? ~0ull : ((1ull << (n & 63u)) - 1ull);
+            changed |= m != (wc & valid);
+            differs_prev |= m != (wp & valid);
+        }
         const uint32_t p = cursor + (uint32_t)mbcnt64(m);
         // (selections by bit mask, not by ?: -- two selects on one condition were turned into an if / else with a store
         // in each arm, i.e. into branches inside the chunk)
@@ -758,25 +709,51 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
         lds_f32* w = ring + lp;
         w[0] = r.x; w[kLdw] = r.y; w[2 * kLdw] = r.z;
         cursor += (uint32_t)__popcll(m);
+        return m;
     };
     // Four full chunks per round: the reads of the groups the earlier rounds completed, then the four chunks' arithmetic
     // as ONE basic block (so that the waits for their loads count precisely), then the adds of those groups.
     // The first round is PEELED out of the loop: the wait counts inside a loop must hold for the way it is entered as
     // well, and entered straight from the four back-to-back prologue loads they came out as vmcnt(7) where the steady
     // state allows vmcnt(15) -- every chunk then waited for loads issued one chunk earlier.
+    // The mask words of a round's four chunks are loaded a round ahead like the points: lane j holds the words of chunk
+    // c + (j & 3), the round copies them to scalars (v_readlane) and requests the next round's at once.
     uint32_t c = 0;
     if (nfull >= 4) {
         P4 r0 = w1_load(nd, 0 * kWave + lane), r1 = w1_load(nd, 1 * kWave + lane), r2 = w1_load(nd, 2 * kWave + lane), r3 = w1_load(nd, 3 * kWave + lane);
         const uint32_t lastfull = (nfull - 1u) * kWave;
+        const uint32_t lastword = nfull - 1u;
+        auto words_of = [&](g_u64* plane, uint32_t cb) -> unsigned long long {
+            const uint32_t w = cb + ((uint32_t)lane & 3u);
+            return plane[w < lastword ? w : lastword];
+        };
+        auto lane_word = [](unsigned long long v, int k) -> unsigned long long {
+            return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), k) << 32) |
+                   (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, k);
+        };
+        unsigned long long WC = 0, WP = 0;
+        if (MODE == kMaskPlane) { WC = words_of(nd.mcur, 0); WP = words_of(nd.mprev, 0); }
         auto round = [&]() __attribute__((always_inline)) {
             // (the reloads clamp to the last full chunk: loads past it would be wasted, never wrong)
             const uint32_t b4 = (c + 4) * kWave, b5 = b4 + kWave, b6 = b5 + kWave, b7 = b6 + kWave;
+            unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+            if (MODE == kMaskPlane) {
+                c0 = lane_word(WC, 0); c1 = lane_word(WC, 1); c2 = lane_word(WC, 2); c3 = lane_word(WC, 3);
+                p0 = lane_word(WP, 0); p1 = lane_word(WP, 1); p2 = lane_word(WP, 2); p3 = lane_word(WP, 3);
+                WC = words_of(nd.mcur, c + 4); WP = words_of(nd.mprev, c + 4);
+            }
             ch.reserve(cursor + 4u * kWave);
             __builtin_amdgcn_sched_barrier(0);
-            step(r0, c, yes());     r0 = w1_load(nd, (b4 < lastfull ? b4 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
-            step(r1, c + 1, yes()); r1 = w1_load(nd, (b5 < lastfull ? b5 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
-            step(r2, c + 2, yes()); r2 = w1_load(nd, (b6 < lastfull ? b6 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
-            step(r3, c + 3, yes()); r3 = w1_load(nd, (b7 < lastfull ? b7 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long m0 = step(r0, c, c0, p0, yes());     r0 = w1_load(nd, (b4 < lastfull ? b4 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long m1 = step(r1, c + 1, c1, p1, yes()); r1 = w1_load(nd, (b5 < lastfull ? b5 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long m2 = step(r2, c + 2, c2, p2, yes()); r2 = w1_load(nd, (b6 < lastfull ? b6 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long m3 = step(r3, c + 3, c3, p3, yes()); r3 = w1_load(nd, (b7 < lastfull ? b7 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            // the round's four new mask words in ONE store: lane j writes the word of chunk c + (j & 3) (sixteen lanes per word)
+            {
+                const uint32_t k = (uint32_t)lane & 3u;
+                const unsigned long long lo = (k & 1u) ? m1 : m0, hi = (k & 1u) ? m3 : m2;
+                nd.mnew[c + k] = (k & 2u) ? hi : lo;
+            }
             ch.consume(rowp, cursor >> 6);                            // the slots this round completed
             c += 4;
         };
@@ -785,20 +762,26 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
     }
     for (; c < nfull; ++c) {                                       // up to three full chunks left
         const P4 r = w1_load(nd, c * kWave + lane);
+        unsigned long long wc = 0, wp = 0;
+        if (MODE == kMaskPlane) { wc = mask_word(nd.mcur, c); wp = mask_word(nd.mprev, c); }
         ch.reserve(cursor + kWave);
-        step(r, c, yes()); ch.consume(rowp, cursor >> 6);
+        nd.mnew[c] = step(r, c, wc, wp, yes());                      // (every lane the same word to the same address)
+        ch.consume(rowp, cursor >> 6);
     }
     if (nfull * kWave < n) {                                       // the partial chunk
         const uint32_t i = nfull * kWave + lane;
         const P4 r = w1_load(nd, i < n ? i : n - 1u);
+        unsigned long long wc = 0, wp = 0;
+        if (MODE == kMaskPlane) { wc = mask_word(nd.mcur, nfull); wp = mask_word(nd.mprev, nfull); }
         ch.reserve(cursor + kWave);
-        step(r, nfull, no()); ch.consume(rowp, cursor >> 6);
+        nd.mnew[nfull] = step(r, nfull, wc, wp, no());
+        ch.consume(rowp, cursor >> 6);
     }
     ch.finish(ring, rowp, cursor, lane);
     FusedOut o;
     o.count = cursor;
-    o.changed = ballot64(changed) != 0ull ? 1u : 0u;
-    o.differs_prev = ballot64(differs_prev) != 0ull ? 1u : 0u;
+    o.changed = changed ? 1u : 0u;
+    o.differs_prev = differs_prev ? 1u : 0u;
     o.sx = ch.result(0); o.sy = ch.result(1); o.sz = ch.result(2);
     return o;
 }
@@ -1519,7 +1502,7 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
     const PatchDesc pd = p.patches[linear];
     const uint32_t fo = p.frame_off[frame];
 
-    W1 cx; cx.sx = p.sx; cx.sy = p.sy; cx.sz = p.sz; cx.il = reinterpret_cast<uint32_t*>(p.ax); cx.mask = p.mask; cx.sh = &sh;
+    W1 cx; cx.sx = p.sx; cx.sy = p.sy; cx.sz = p.sz; cx.il = reinterpret_cast<uint32_t*>(p.ax); cx.sh = &sh;
     cx.base = pd.begin; cx.lane = lane; cx.addends = 0ull;
     const rpw_config& cfg = p.cfg;
     uint32_t* stk = sh.stk;
@@ -1537,7 +1520,7 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
     float mean_dist, root_zmn, root_zmx;
     {
         NodeRef root; root.x = (g_cf32*)(p.sx + cx.base); root.y = (g_cf32*)(p.sy + cx.base); root.z = (g_cf32*)(p.sz + cx.base);
-        root.m = (g_u8*)(p.mask + cx.base); root.il = (g_u32*)(cx.il + cx.base); root.n = pd.n;
+        root.mnew = root.mcur = root.mprev = nullptr; root.il = (g_u32*)(cx.il + cx.base); root.n = pd.n;      // (the range sweep touches no mask)
         Sums6 sum;
         W1_PH(1, pd.n, sum = W_SWEEP(root, pd.n, kSweepRange, 0, no_prm))
         cx.addends += pd.n;
@@ -1549,6 +1532,11 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
 
     PatchAcc pa; pa.nodes = 0; pa.splits = 0; pa.maxdepth = 0; pa.ground = 0; pa.iters = 0;
     bool permuted = false;
+    // the patch's words of the three mask planes (patch p of the batch starts at word (begin >> 6) + p: ceil(n / 64) words fit in front of
+    // the next patch's); mC = the current mask, mQ = the one before it, mF = free for the next pass to write
+    g_u64* mC = (g_u64*)p.mbits + ((size_t)(pd.begin >> 6) + linear);
+    g_u64* mQ = mC + p.mplane;
+    g_u64* mF = mQ + p.mplane;
 
     int sp = 0;
     if (lane == 0) { stk[0] = 0; stk[1] = pd.n; stk[2] = 0; }
@@ -1565,7 +1553,6 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
         const float* gx = p.sx + cx.base + s;
         const float* gy = p.sy + cx.base + s;
         const float* gz = p.sz + cx.base + s;
-        uint8_t* gm = p.mask + cx.base + s;
         const uint32_t* gi = p.sidx + cx.base + s;
         uint32_t* gl = cx.il + cx.base + s;
 
@@ -1610,7 +1597,8 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
             const uint32_t idx = (uint32_t)(0.1f * (float)n);     // static_cast<size_t>(0.1f * size)
             z_th = w1_select_rank(cx, s, n, 2, idx < n ? idx : n - 1) + cfg.th_seeds;
         }
-        NodeRef nd; nd.x = (g_cf32*)gx; nd.y = (g_cf32*)gy; nd.z = (g_cf32*)gz; nd.m = (g_u8*)gm; nd.il = (g_u32*)gl; nd.n = n;
+        NodeRef nd; nd.x = (g_cf32*)gx; nd.y = (g_cf32*)gy; nd.z = (g_cf32*)gz; nd.mnew = mF; nd.mcur = mC; nd.mprev = mQ; nd.il = (g_u32*)gl; nd.n = n;
+        auto rotate = [&]() { g_u64* t = mQ; mQ = mC; mC = mF; mF = t; nd.mnew = mF; nd.mcur = mC; nd.mprev = mQ; };      // a pass wrote mF: it is the current mask now
         MaskPrm mp; mp.cx = mp.cy = mp.cz = 0.0f; mp.nx = mp.ny = 0.0f; mp.nz = 1.0f; mp.thr = z_th;
         float cs[3];                                   // centroid sums of the current mask
         uint32_t count;
@@ -1619,10 +1607,12 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
             W1_PH(2, n, fo_ = W_FUSED(nd, kMaskSeed, mp))
             count = fo_.count; cs[0] = fo_.sx; cs[1] = fo_.sy; cs[2] = fo_.sz;
             cx.addends += count;
+            rotate();
         }
         if (count < 3) {
             const Sel3 sel = w1_three_lowest(cx, s, n);
-            for (uint32_t i = lane; i < n; i += kFit1Threads) gm[i] = (i == sel.v[0] || i == sel.v[1] || i == sel.v[2]) ? 1 : 0;
+            for (uint32_t i = lane; i < n + (uint32_t)lane; i += kFit1Threads)          // (whole chunks: every lane takes part in the ballot)
+                mC[i >> 6] = ballot64(i < n && (i == sel.v[0] || i == sel.v[1] || i == sel.v[2]));
             // the index list in slot order: the three slots, ascending (entries as wide as the passes read them)
             uint32_t a = sel.v[0], b = sel.v[1], c = sel.v[2], t;
             if (a > b) { t = a; a = b; b = t; }
@@ -1673,6 +1663,7 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
             mp.cx = pl.cx; mp.cy = pl.cy; mp.cz = pl.cz; mp.nx = pl.nx; mp.ny = pl.ny; mp.nz = pl.nz; mp.thr = threshold;
             FusedOut mo;                                         // new mask + its index list + its centroid sums
             W1_PH(2, n, mo = W_FUSED(nd, kMaskPlane, mp))
+            rotate();
             const uint32_t newcount = mo.count;
             cx.addends += newcount;
             const bool any_changed = mo.changed != 0, any_differs_prev = mo.differs_prev != 0;
@@ -1774,12 +1765,16 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
         for (uint32_t i0 = lane; i0 < n; i0 += 4 * kFit1Threads) {
             uint32_t orig[4], m[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * kFit1Threads, ic = i < n ? i : n - 1u; orig[u] = gi[ic]; m[u] = gm[ic]; }
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * kFit1Threads, ic = i < n ? i : n - 1u;
+                orig[u] = gi[ic];
+                m[u] = (uint32_t)(((final_bit ? mQ : mC)[ic >> 6] >> (ic & 63u)) & 1ull);      // the final mask's plane: the older one after a period-2 ending
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t i = i0 + u * kFit1Threads;
                 if (i >= n) continue;
-                p.labels[fo + orig[u]] = ((m[u] >> final_bit) & 1u) ? RPW_LABEL_GROUND : RPW_LABEL_NONGROUND;
+                p.labels[fo + orig[u]] = m[u] ? RPW_LABEL_GROUND : RPW_LABEL_NONGROUND;
                 if (p.residual) {
                     float x, y, z;
                     if (permuted) {
@@ -1886,7 +1881,7 @@ __global__ void debug_eig3_kernel(const float* cov, float* nrm, uint32_t n)
 // micro-benchmark of the two loops patch_fit1 lives in (test hook rpw_debug_loop_bench): every block runs `reps`
 // chain sweeps (what = sweep mode) or mask passes (what = 16 + mask mode) over its own synthetic node of n slots
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kFit1Threads, 4) void w1_loop_bench_kernel(const float* sx, const float* sy, const float* sz, uint8_t* mask,
+__global__ __launch_bounds__(kFit1Threads, 4) void w1_loop_bench_kernel(const float* sx, const float* sy, const float* sz, unsigned long long* mw, uint32_t mplane,
                                                                             uint32_t* il, uint32_t n, uint32_t count, int what, int reps, float* out, unsigned long long* ticks)
 {
     __shared__ Fit1Shared sh;
@@ -1894,7 +1889,7 @@ __global__ __launch_bounds__(kFit1Threads, 4) void w1_loop_bench_kernel(const fl
     lds_f32* ring = (lds_f32*)sh.ring;
     const size_t base = (size_t)blockIdx.x * n;
     NodeRef nd; nd.x = (g_cf32*)(sx + base); nd.y = (g_cf32*)(sy + base); nd.z = (g_cf32*)(sz + base);
-    nd.m = (g_u8*)(mask + base); nd.il = (g_u32*)(il + base); nd.n = n;
+    nd.mcur = (g_u64*)mw + (base >> 6) + blockIdx.x; nd.mprev = nd.mcur + mplane; nd.mnew = nd.mprev + mplane; nd.il = (g_u32*)(il + base); nd.n = n;
     float acc = 0.0f;
     const unsigned long long tick0 = __builtin_readcyclecounter();      // shader clock (s_memtime): the chip's clock depends on its recent load
     for (int r = 0; r < reps; ++r) {
@@ -1918,7 +1913,7 @@ __global__ __launch_bounds__(kFit1Threads, 4) void w1_loop_bench_kernel(const fl
 }
 
 // the same loops in the chain-server form: workgroup b's feeder f runs them on node b * kSrvFeeders + f
-__global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void srv_loop_bench_kernel(const float* sx, const float* sy, const float* sz, uint8_t* mask,
+__global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void srv_loop_bench_kernel(const float* sx, const float* sy, const float* sz, unsigned long long* mw, uint32_t mplane,
                                                                                      uint32_t* il, uint32_t n, uint32_t count, int what, int reps, uint32_t nodes, float* out, unsigned long long* ticks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char srv_lds[];
@@ -1932,7 +1927,7 @@ __global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void srv_loop_bench_k
         lds_f32* ring = (lds_f32*)shs[f].ring;
         const size_t base = (size_t)node * n;
         NodeRef nd; nd.x = (g_cf32*)(sx + base); nd.y = (g_cf32*)(sy + base); nd.z = (g_cf32*)(sz + base);
-        nd.m = (g_u8*)(mask + base); nd.il = (g_u32*)(il + base); nd.n = n;
+        nd.mcur = (g_u64*)mw + (base >> 6) + node; nd.mprev = nd.mcur + mplane; nd.mnew = nd.mprev + mplane; nd.il = (g_u32*)(il + base); nd.n = n;
         float acc = 0.0f;
         const unsigned long long tick0 = __builtin_readcyclecounter();
         for (int r = 0; r < reps; ++r) {
@@ -1952,7 +1947,7 @@ __global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void srv_loop_bench_k
 }
 
 // ... and with one server per node: workgroup b = server wave + the feeder of node b
-__global__ __launch_bounds__(2 * kWave, 4) void srv1_loop_bench_kernel(const float* sx, const float* sy, const float* sz, uint8_t* mask,
+__global__ __launch_bounds__(2 * kWave, 4) void srv1_loop_bench_kernel(const float* sx, const float* sy, const float* sz, unsigned long long* mw, uint32_t mplane,
                                                                       uint32_t* il, uint32_t n, uint32_t count, int what, int reps, float* out, unsigned long long* ticks)
 {
     __shared__ SrvShared sv;
@@ -1964,7 +1959,7 @@ __global__ __launch_bounds__(2 * kWave, 4) void srv1_loop_bench_kernel(const flo
     lds_f32* ring = (lds_f32*)sh.ring;
     const size_t base = (size_t)blockIdx.x * n;
     NodeRef nd; nd.x = (g_cf32*)(sx + base); nd.y = (g_cf32*)(sy + base); nd.z = (g_cf32*)(sz + base);
-    nd.m = (g_u8*)(mask + base); nd.il = (g_u32*)(il + base); nd.n = n;
+    nd.mcur = (g_u64*)mw + (base >> 6) + blockIdx.x; nd.mprev = nd.mcur + mplane; nd.mnew = nd.mprev + mplane; nd.il = (g_u32*)(il + base); nd.n = n;
     float acc = 0.0f;
     const unsigned long long tick0 = __builtin_readcyclecounter();
     for (int r = 0; r < reps; ++r) {
@@ -2116,19 +2111,19 @@ void launch_frame_copy_out(const uint8_t* labels, uint8_t* h_labels, uint32_t n,
     if (blocks > 64) blocks = 64;
     hipLaunchKernelGGL(frame_copy_out_kernel, dim3(blocks), dim3(256), 0, s, labels, h_labels, n, res, h_res, stats, h_stats, fit_error);
 }
-void launch_loop_bench(const float* sx, const float* sy, const float* sz, uint8_t* mask, uint32_t* il, uint32_t n, uint32_t count,
+void launch_loop_bench(const float* sx, const float* sy, const float* sz, unsigned long long* mw, uint32_t mplane, uint32_t* il, uint32_t n, uint32_t count,
                        int what, int reps, uint32_t blocks, float* out, unsigned long long* ticks, hipStream_t s)
 {
     const int w = 1 + (what >> 5);      // what + 64: the same loop in the chain-server form (seven nodes per server), + 96: one server per node
     what &= 31;
-    if (w == 4) { hipLaunchKernelGGL(srv1_loop_bench_kernel, dim3(blocks), dim3(2 * kWave), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out, ticks); return; }
+    if (w == 4) { hipLaunchKernelGGL(srv1_loop_bench_kernel, dim3(blocks), dim3(2 * kWave), 0, s, sx, sy, sz, mw, mplane, il, n, count, what, reps, out, ticks); return; }
     if (w == 3) {
         allow_srv_lds(reinterpret_cast<const void*>(srv_loop_bench_kernel));
         const uint32_t wgs = (blocks + (uint32_t)kSrvFeeders - 1u) / (uint32_t)kSrvFeeders;
-        hipLaunchKernelGGL(srv_loop_bench_kernel, dim3(wgs), dim3(kWave * (1 + kSrvFeeders)), kSrvLdsBytes, s, sx, sy, sz, mask, il, n, count, what, reps, blocks, out, ticks);
+        hipLaunchKernelGGL(srv_loop_bench_kernel, dim3(wgs), dim3(kWave * (1 + kSrvFeeders)), kSrvLdsBytes, s, sx, sy, sz, mw, mplane, il, n, count, what, reps, blocks, out, ticks);
         return;
     }
-    hipLaunchKernelGGL(w1_loop_bench_kernel, dim3(blocks), dim3(kFit1Threads), 0, s, sx, sy, sz, mask, il, n, count, what, reps, out, ticks);
+    hipLaunchKernelGGL(w1_loop_bench_kernel, dim3(blocks), dim3(kFit1Threads), 0, s, sx, sy, sz, mw, mplane, il, n, count, what, reps, out, ticks);
 }
 void launch_debug_angles(const float* x, const float* y, float* a, uint32_t n, hipStream_t s)
 {
