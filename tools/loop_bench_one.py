@@ -1,4 +1,4 @@
-"""One loop of tools/loop_bench.py, for a profiler run:  python tools/loop_bench_one.py <what> <nodes> [n]   (what + 32: two-wave form, + 64: chain-server form)"""
+"""One loop of tools/loop_bench.py, for a profiler run:  python tools/loop_bench_one.py <what> <nodes> [n]   (what + 64: chain-server form, + 96: a server per node)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rpw_amd
