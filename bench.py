@@ -477,6 +477,39 @@ def main():
         torch.cuda.synchronize()
         host_path = host_path_legs(rpw_amd, cfg_kw, frames, local_rank)
 
+    # The same frames as four quarter batches in flight on four streams (how a caller with a continuous supply of batches
+    # would drive the library: the binning of one batch and the tail of another overlap a third's plane fits). Informational,
+    # never `value`: with launches sharing the chip a kernel's launch duration is no longer its own.
+    staggered = None
+    if world == 1 and n_streams == 1 and not args.no_host_path and F >= 8:
+        q = F // 4
+        q_off = np.ascontiguousarray(offsets[: q + 1])
+        q_pts = int(q_off[-1])
+        q_eng = [rpw_amd.Engine(rpw_amd.PatchworkConfig(**cfg_kw), device=local_rank, max_points=q_pts, max_frames=q) for _ in range(4)]
+        q_str = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        q_lab = [torch.empty(q_pts, dtype=torch.uint8, device=dev) for _ in range(4)]
+
+        def q_step(i):
+            k = i % 4
+            q_eng[k].segment_batch_device(d_xyz.data_ptr(), q_off, q_lab[k].data_ptr(), None, q_str[k].cuda_stream)
+        for i in range(8):
+            q_step(i)
+        torch.cuda.synchronize()
+        n_q = 4 * max(4, args.steps)
+        t1 = time.perf_counter()
+        for i in range(n_q):
+            q_step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        for e in q_eng:
+            e.batch_stats(q)                                        # (raises on patch_fit's error flag)
+        same = bool(torch.equal(q_lab[0], d_labels[:q_pts]))
+        staggered = {"frames_per_sec": round(q * n_q / dt, 2), "batches_in_flight": 4, "frames_per_batch": q, "steps": n_q,
+                     "ms_per_batch": round(1e3 * dt / n_q, 4), "labels_equal_the_single_batch_run": same}
+        for e in q_eng:
+            e.close()
+        del q_lab
+
     # PCIe-inclusive BATCH pipeline, informational (SURVEY.md 8d "end-to-end"): every batch is copied in from pinned host
     # memory and its labels are copied back, on the batch's own stream, so copies overlap other batches' kernels
     e2e = None
@@ -539,6 +572,7 @@ def main():
             "single_frame_latency_ms": None if lat is None else lat["median"],
             "single_frame_latency": lat,
             "host_path": host_path,
+            "four_batches_in_flight": staggered,
         }
         if gather_check is not None:
             out["result_gather"] = gather_check
