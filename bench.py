@@ -154,6 +154,11 @@ def gather_records(local_rec, world):
     import torch.distributed as dist
     if world <= 1:
         return local_rec.clone()
+    if dist.get_backend() == "gloo" and local_rec.is_cuda:      # one-GPU rehearsal: gloo gathers host tensors
+        torch.cuda.current_stream().synchronize()
+        host = torch.empty(local_rec.numel() * world, dtype=local_rec.dtype)
+        dist.all_gather_into_tensor(host, local_rec.cpu())
+        return host.to(local_rec.device)
     out = torch.empty(local_rec.numel() * world, dtype=local_rec.dtype, device=local_rec.device)
     dist.all_gather_into_tensor(out, local_rec)
     return out
@@ -172,6 +177,10 @@ def gather_label_slabs(local_labels, world):
     mine[: local_labels.numel()] = local_labels
     if world <= 1:
         return mine.reshape(1, slab), slab
+    if dist.get_backend() == "gloo" and mine.is_cuda:
+        host = torch.empty(world * slab, dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, mine.cpu())
+        return host.to(mine.device).reshape(world, slab), slab
     out = torch.empty(world * slab, dtype=torch.uint8, device=local_labels.device)
     dist.all_gather_into_tensor(out, mine)
     return out.reshape(world, slab), slab
@@ -318,6 +327,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 code path on a box with ONE GPU (RPW_BENCH_REHEARSE_ONE_GPU=1, never set by the driver): every
+    # rank uses GPU 0 and the collectives go over gloo, since RCCL refuses two ranks on one device. The line it prints is
+    # marked "rehearsal" and is not a measurement of anything.
+    rehearse = os.environ.get("RPW_BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     if not torch.cuda.is_available():
@@ -326,7 +341,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     wl_gen, cfg_kw, wl_frames, wl_desc = WORKLOADS[args.workload]      # c2 = configs[1]: recursion depth = 3
     if args.frames <= 0:
@@ -574,6 +592,8 @@ def main():
             "host_path": host_path,
             "four_batches_in_flight": staggered,
         }
+        if rehearse:
+            out["rehearsal"] = "every rank on GPU 0, collectives over gloo: a run of the N > 1 code path, not a measurement"
         if gather_check is not None:
             out["result_gather"] = gather_check
         if e2e is not None:

@@ -2092,7 +2092,9 @@ void launch_fit(const DevParams& p, hipStream_t s)
     // chain-server form: persistent workgroups (two fit a CU), each feeder pulls patches until the work counter runs out
     allow_srv_lds(reinterpret_cast<const void*>(patch_fit_srv_kernel));
     uint32_t wgs = (grid + (uint32_t)kSrvFeeders - 1u) / (uint32_t)kSrvFeeders;
-    if (wgs > 2u * 256u) wgs = 2u * 256u;
+    // RPW_SRV_WGS=k (experiments): fewer persistent workgroups than fit the chip, i.e. fewer patches in flight
+    static const uint32_t cap = [] { const char* e = getenv("RPW_SRV_WGS"); const int k = e ? atoi(e) : 0; return (k > 0 && k < 512) ? (uint32_t)k : 2u * 256u; }();
+    if (wgs > cap) wgs = cap;
     hipLaunchKernelGGL(patch_fit_srv_kernel, dim3(wgs), dim3(kWave * (1 + kSrvFeeders)), kSrvLdsBytes, s, p);
 }
 void launch_result_record(const rpw_frame_stats* stats, int32_t* out, uint32_t n_frames, const uint32_t* fit_error, hipStream_t s)
