@@ -700,10 +700,13 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
         // (selections by bit mask, not by ?: -- two selects on one condition were turned into an if / else with a store
         // in each arm, i.e. into branches inside the chunk)
         const uint32_t sel = 0u - (uint32_t)in;
-        // index list (for the covariance sweep): an inlier to its place, everybody else into the last entry
-        const uint32_t ip = (p & sel) | ((n - 1u) & ~sel);
-        if (FULL) il_store<IW>(il, ip, i);
-        else if (ok) il_store<IW>(il, ip, i);
+        // index list (for the single-wave form's covariance sweep; IW == 0, the server forms: none, their sweeps read the mask):
+        // an inlier to its place, everybody else into the last entry
+        if (IW) {
+            const uint32_t ip = (p & sel) | ((n - 1u) & ~sel);
+            if (FULL) il_store<(IW ? IW : 4)>(il, ip, i);
+            else if (ok) il_store<(IW ? IW : 4)>(il, ip, i);
+        }
         // centroid addends: an inlier to its place in the ring, everybody else into the dump entries
         const uint32_t lp = (fused_ring_pos(p) & sel) | (((uint32_t)kFDump + (uint32_t)lane) & ~sel);
         lds_f32* w = ring + lp;
@@ -1072,6 +1075,9 @@ __device__ __attribute__((noinline)) N3 w1_normal(float a00, float a10, float a1
 // One wave's LDS operations are performed in order, so "addends, then the count" / "accumulator, then cons" need no fence.
 // Waits are polls with s_sleep and a spin limit (a protocol error ends the launch with an error flag, not a hung GPU).
 // ==========================================================================================
+#ifndef RPW_SRV1_MASKED
+#define RPW_SRV1_MASKED 0               // 1: the server-per-patch form takes the inliers from the mask planes too (no index list)
+#endif
 constexpr int kSrvFeeders = 7;
 constexpr int kSrvSweepSlots = 4;        // ring slots of a sweep (6 rows of 64 each); the fused pass uses kFSlots slots of 3 rows
 #ifndef RPW_SWEEP_DEPTH
@@ -1301,20 +1307,127 @@ __device__ __attribute__((noinline)) void srv1_loop(SrvShared* sv, Fit1Shared* s
 #undef RPW_LDS_WAIT8
 }
 
+// The inliers' slot numbers, 64 at a time and in slot order, made from a mask plane (server forms: their fused pass writes
+// no index list, and their sweeps read 0.125 B per slot of mask words instead of 2 B per inlier written and read again).
+// Lane j keeps words wb + j and wb + 64 + j of the plane (8192 slots per block; a larger node reloads -- the one place where
+// this waits for memory). Words are expanded a BATCH at a time by all 64 lanes: lane l takes piece l of the batch (PB bits:
+// a byte of one of 8 words, or for nodes beyond 65536 slots a nibble of one of 4), fetched from the lane that holds the word
+// (ds_bpermute); an exclusive scan of the pieces' popcounts (DPP) gives every lane the place of its first inlier, and its
+// up to PB slot numbers go to consecutive entries of a circular LDS buffer, from where the sweep takes 64 consecutive
+// entries per slot (one wave's LDS operations are performed in order). ~130 instructions per batch of 512 slots, i.e. ~30
+// per 64 inliers at the bench's 56 %; word by word (one mbcnt per word) it was ~70, which a lone feeder could not hide.
+// `count` must be the number of set bits of the node's words (the passes that write the masks return it); a mismatch cannot
+// run away: the word cursor stops at the node's last word and the result is clamped to the node.
+constexpr int kIdxBufBytes = 2048;                                 // 1024 16-bit or 512 32-bit entries
+constexpr int kIdxBufAt = kSrvSweepSlots * kSlotFloats;            // behind the sweep ring's slots, in floats ...
+static_assert(offsetof(Fit1Shared, hist) == sizeof(float) * kRingFloats, "... and on into hist (select_rank's, idle during a sweep)");
+static_assert(kIdxBufAt * 4 + kIdxBufBytes <= (int)(sizeof(float) * kRingFloats + sizeof(uint32_t) * 256), "the index buffer must fit");
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
+{
+    // rows of 16 lanes: shifts by 1, 2, 4, 8 with zero fill; then lane 15 of a row to the row behind it, lane 31 to rows 2 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+template <int PB>                      // bits per piece: 8 (16-bit entries, nodes of up to 65536 slots) or 4 (32-bit entries)
+struct IdxGen {
+    static constexpr int PW = 64 / PB;                 // pieces per word
+    static constexpr int WPB = kWave / PW;             // words per batch
+    static constexpr uint32_t kEntries = PB == 8 ? (uint32_t)kIdxBufBytes / 2u : (uint32_t)kIdxBufBytes / 4u;
+    static_assert(kEntries >= (uint32_t)(kWave * PB + kWave), "a batch's inliers next to the unread rest of a slot");
+    g_u64* words;
+    uint32_t ib;                       // LDS byte address of the buffer
+    uint32_t nw, count, n;
+    uint32_t wc, wb, filled;           // next word to expand, first word of the block in W0 / W1, inliers expanded so far (wave-uniform)
+    uint32_t W0lo, W0hi, W1lo, W1hi;
+    int lane;
+    // (the empty asm "uses" the words right here: the wait for the two loads is placed in this rarely executed block, where
+    // it costs one memory latency per 8192 slots; without it the wait sat in front of EVERY expansion as vmcnt(0), i.e.
+    // every call drained the sweep's prefetched point loads)
+    __device__ __forceinline__ void load_block(uint32_t w0)
+    {
+        wb = w0;
+        const uint32_t a = w0 + (uint32_t)lane, b = a + 64u;
+        const unsigned long long x = words[a < nw ? a : nw - 1u], y = words[b < nw ? b : nw - 1u];
+        W0lo = (uint32_t)x; W0hi = (uint32_t)(x >> 32); W1lo = (uint32_t)y; W1hi = (uint32_t)(y >> 32);
+        asm volatile("" : "+v"(W0lo), "+v"(W0hi), "+v"(W1lo), "+v"(W1hi));
+    }
+    __device__ __forceinline__ void begin(g_u64* plane, uint32_t n_, uint32_t count_, lds_f32* ring, int ln)
+    {
+        words = plane; n = n_; count = count_; nw = (n_ + 63u) >> 6; lane = ln;
+        ib = (uint32_t)(uintptr_t)ring + (uint32_t)kIdxBufAt * 4u;
+        wc = 0; filled = 0;
+        load_block(0);
+    }
+    __device__ __forceinline__ void expand()
+    {
+        if (wc - wb >= 128u) load_block(wc);
+        const uint32_t k = wc - wb;                                  // a multiple of WPB: a batch lies in W0 or in W1
+        const uint32_t w = (uint32_t)lane / (uint32_t)PW, piece = (uint32_t)lane % (uint32_t)PW;
+        const int src = (int)((((k & 63u) + w) & 63u) * 4u);
+        const bool upper = k >= 64u;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(upper ? W1lo : W0lo));
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(upper ? W1hi : W0hi));
+        const uint32_t half = piece < (uint32_t)(PW / 2) ? lo : hi;
+        uint32_t bits = (half >> ((piece % (uint32_t)(PW / 2)) * (uint32_t)PB)) & ((1u << PB) - 1u);
+        if (wc + w >= nw) bits = 0u;                                 // (the clamped loads repeat the node's last word)
+        const uint32_t cnt = (uint32_t)__builtin_popcount(bits);
+        const uint32_t incl = wave_incl_scan_dpp(cnt);
+        uint32_t pos = filled + incl - cnt;
+        const uint32_t slot0 = wc * (uint32_t)kWave + (uint32_t)lane * (uint32_t)PB;      // the slot of the piece's bit 0
+#pragma unroll
+        for (int it = 0; it < PB; ++it) {
+            if (ballot64(bits != 0u) == 0ull) break;
+            if (bits) {
+                const uint32_t v = slot0 + (uint32_t)(__builtin_ctz(bits));
+                const uint32_t e = pos & (kEntries - 1u);
+                if (PB == 8) *(__attribute__((address_space(3))) uint16_t*)(uintptr_t)(ib + e * 2u) = (uint16_t)v;
+                else         *(lds_word*)(uintptr_t)(ib + e * 4u) = v;
+                ++pos;
+                bits &= bits - 1u;
+            }
+        }
+        filled += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        wc += (uint32_t)WPB;
+    }
+    // the slot numbers of inliers [64 u, 64 u + 64) (lanes past the last inlier repeat it); u must not decrease between calls
+    __device__ __forceinline__ uint32_t next(uint32_t u)
+    {
+        const uint32_t end = (u + 1u) * (uint32_t)kWave, target = end < count ? end : count;
+        while (filled < target && wc < nw) expand();
+        asm volatile("" ::: "memory");
+        const uint32_t j = u * (uint32_t)kWave + (uint32_t)lane, last = count - 1u, jc = j < last ? j : last;
+        const uint32_t e = jc & (kEntries - 1u);
+        uint32_t idx;
+        if (PB == 8) idx = (uint32_t)*(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)(ib + e * 2u);
+        else         idx = *(const lds_word*)(uintptr_t)(ib + e * 4u);
+        asm volatile("" ::: "memory");
+        return idx < n ? idx : n - 1u;
+    }
+};
+
 // feeder half of a chain sweep: slot s goes to ring slot s % kSrvSweepSlots once the
 // server has added slot s - kSrvSweepSlots
-template <int MODE, int IW>
+template <int MODE, int SRC>        // SRC: 0 = every slot of the node; 1 / 3 = the inliers of plane nd.mcur (node of up to / beyond 65536 slots); 2 / 4 = the index list (bytes per entry)
 __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t count, const SweepPrm& prm, lds_f32* ring, const SrvPort& pt, int lane)
 {
     constexpr int K = SweepRows<MODE>::K;
     typedef float f2 __attribute__((ext_vector_type(2)));
-    typedef __attribute__((address_space(1))) const char g_cchar;
-    g_cchar* il = reinterpret_cast<g_cchar*>(nd.il);
     const uint32_t nslots = (count + kWave - 1) / kWave;
     const uint32_t last = count - 1u;
+    typedef __attribute__((address_space(1))) const char g_cchar;
+    g_cchar* il = reinterpret_cast<g_cchar*>(nd.il);
+    constexpr bool MASKED = SRC == 1 || SRC == 3;
+    IdxGen<(SRC == 3 ? 4 : 8)> gen;
+    if (MASKED) gen.begin(nd.mcur, nd.n, count, ring, lane);
     auto index_of = [&](uint32_t u) -> uint32_t {
+        if (MASKED) return gen.next(u);
         const uint32_t j = u * kWave + lane, jc = j < last ? j : last;
-        return IW ? il_load<(IW ? IW : 4)>(il, jc) : jc;
+        return SRC ? il_load<(SRC == 2 ? 2 : 4)>(il, jc) : jc;
     };
     auto point_of = [&](uint32_t idx) -> X3 {
         X3 q; q.x = ldg_f32(nd.x, idx); q.y = ldg_f32(nd.y, idx);
@@ -1376,6 +1489,12 @@ __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t coun
     return out;
 }
 
+// MASKED (the batch form): the inliers come from the mask plane; else (a server per patch) from the index list the fused pass
+// wrote. Turning mask words into slot numbers costs the feeder ~70 instructions per slot of 64 inliers: among seven feeders
+// and two workgroups per CU they disappear and the bench batch gains 2.4 % from the 2 B per inlier no longer written and
+// read; a LONE feeder issues one instruction per ~6 cycles, its covariance sweep went from 9.7 to 16.7 cycles per inlier
+// (the server waits for it) and a single frame from 2.48 to 3.13 ms -- so the latency form keeps the list.
+template <bool MASKED>
 __device__ __attribute__((noinline)) Sums6 srv_chain_sweep(NodeRef nd_in, uint32_t count, int mode, SweepPrm prm, lds_f32* ring, SrvShared* sv, int f)
 {
     const int lane = threadIdx.x & 63;
@@ -1390,14 +1509,17 @@ __device__ __attribute__((noinline)) Sums6 srv_chain_sweep(NodeRef nd_in, uint32
     for (int k = 0; k < 6; ++k) out.v[k] = 0.0f;
     if (count == 0) return out;
     const bool narrow = nd.n <= 65536u;                // the width the pass that wrote the list used
+#define RPW_SRV_INDEXED(M) (narrow ? srv_sweep_loop<M, (MASKED ? 1 : 2)>(nd, count, prm, ring, pt, lane)   \
+                                   : srv_sweep_loop<M, (MASKED ? 3 : 4)>(nd, count, prm, ring, pt, lane))
     switch (__builtin_amdgcn_readfirstlane(mode)) {
-    case kSweepCov:   return narrow ? srv_sweep_loop<kSweepCov, 2>(nd, count, prm, ring, pt, lane) : srv_sweep_loop<kSweepCov, 4>(nd, count, prm, ring, pt, lane);
-    case kSweepXYZ:   return narrow ? srv_sweep_loop<kSweepXYZ, 2>(nd, count, prm, ring, pt, lane) : srv_sweep_loop<kSweepXYZ, 4>(nd, count, prm, ring, pt, lane);
-    case kSweepDist:  return narrow ? srv_sweep_loop<kSweepDist, 2>(nd, count, prm, ring, pt, lane) : srv_sweep_loop<kSweepDist, 4>(nd, count, prm, ring, pt, lane);
+    case kSweepCov:   return RPW_SRV_INDEXED(kSweepCov);
+    case kSweepXYZ:   return RPW_SRV_INDEXED(kSweepXYZ);
+    case kSweepDist:  return RPW_SRV_INDEXED(kSweepDist);
     case kSweepRange: return srv_sweep_loop<kSweepRange, 0>(nd, count, prm, ring, pt, lane);
     case kSweepXY:    return srv_sweep_loop<kSweepXY, 0>(nd, count, prm, ring, pt, lane);
     default:          return srv_sweep_loop<kSweepVarXY, 0>(nd, count, prm, ring, pt, lane);
     }
+#undef RPW_SRV_INDEXED
 }
 
 // the fused pass's chain, handed to the server: "consume" publishes, "finish" pads, publishes and collects
@@ -1436,6 +1558,7 @@ struct SrvChain {
     __device__ __forceinline__ float result(int k) const { return sums[k]; }
 };
 
+template <bool LIST>               // LIST: the pass also writes the index list (the latency form's sweeps read it)
 __device__ __attribute__((noinline)) FusedOut srv_fused_pass(NodeRef nd_in, int mode, MaskPrm prm, lds_f32* ring, SrvShared* sv, int f)
 {
     const int lane = threadIdx.x & 63;
@@ -1444,12 +1567,14 @@ __device__ __attribute__((noinline)) FusedOut srv_fused_pass(NodeRef nd_in, int 
     prm.thr = uni(prm.thr);
     ring = (lds_f32*)(uintptr_t)uni((uint32_t)(uintptr_t)ring);
     sv = uni_ptr(sv);
-    const bool narrow = nd.n <= 65536u;
     SrvChain ch;
     ch.begin(srv_port(sv, (int)uni((uint32_t)f)), lane);
+    const bool narrow = nd.n <= 65536u;
     if (uni((uint32_t)mode) == (uint32_t)kMaskPlane)
-        return narrow ? w1_fused_loop<kMaskPlane, 2>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskPlane, 4>(nd, prm, ring, lane, ch);
-    return narrow ? w1_fused_loop<kMaskSeed, 2>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskSeed, 4>(nd, prm, ring, lane, ch);
+        return !LIST ? w1_fused_loop<kMaskPlane, 0>(nd, prm, ring, lane, ch)
+                     : (narrow ? w1_fused_loop<kMaskPlane, (LIST ? 2 : 0)>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskPlane, (LIST ? 4 : 0)>(nd, prm, ring, lane, ch));
+    return !LIST ? w1_fused_loop<kMaskSeed, 0>(nd, prm, ring, lane, ch)
+                 : (narrow ? w1_fused_loop<kMaskSeed, (LIST ? 2 : 0)>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskSeed, (LIST ? 4 : 0)>(nd, prm, ring, lane, ch));
 }
 
 // workgroup set-up and the feeder's good-bye
@@ -1487,16 +1612,16 @@ __device__ __forceinline__ bool patch_of_item(const DevParams& p, uint32_t item,
     return true;
 }
 
-// One patch, on the wave that owns it. W = 1: alone; W = 3: as feeder `feeder` of a chain-server workgroup (a server of
-// seven feeders, or a server of its own).
+// One patch, on the wave that owns it. W = 1: alone; W = 3: as feeder `feeder` of a chain server of seven feeders (the sweeps
+// take the inliers from the mask planes); W = 4: as the feeder of a server of its own (index list, like W = 1).
 template <int W>
 __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, uint32_t linear, int lane, SrvShared* sv, int feeder)
 {
 #define W1_PH(IDX, CNT, ...) { __VA_ARGS__; }
     // the passes that run a chain: everything on this wave (single-wave form), or the feeding half here and the adds on a
     // server wave
-#define W_SWEEP(ND, M, MODE, INDEXED, PRM) (W == 3 ? srv_chain_sweep(ND, M, MODE, PRM, ring, sv, feeder) : w1_chain_sweep(ND, M, MODE, INDEXED, PRM, ring))
-#define W_FUSED(ND, MODE, PRM) (W == 3 ? srv_fused_pass(ND, MODE, PRM, ring, sv, feeder) : w1_fused_pass(ND, MODE, PRM, ring))
+#define W_SWEEP(ND, M, MODE, INDEXED, PRM) (W == 3 ? srv_chain_sweep<true>(ND, M, MODE, PRM, ring, sv, feeder) : (W == 4 ? srv_chain_sweep<false>(ND, M, MODE, PRM, ring, sv, feeder) : w1_chain_sweep(ND, M, MODE, INDEXED, PRM, ring)))
+#define W_FUSED(ND, MODE, PRM) (W == 3 ? srv_fused_pass<false>(ND, MODE, PRM, ring, sv, feeder) : (W == 4 ? srv_fused_pass<true>(ND, MODE, PRM, ring, sv, feeder) : w1_fused_pass(ND, MODE, PRM, ring)))
 #define W_LEAVE() {}
     const int frame = (int)(linear / (uint32_t)p.P), patch = (int)(linear % (uint32_t)p.P);
     const PatchDesc pd = p.patches[linear];
@@ -1645,10 +1770,12 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
             W1_PH(5, 1, nrm = w1_normal(cv.v[0] / fm1, cv.v[1] / fm1, cv.v[2] / fm1, cv.v[3] / fm1, cv.v[4] / fm1, cv.v[5] / fm1))
             pl.nx = nrm.x; pl.ny = nrm.y; pl.nz = nrm.z;
         };
-        auto residual_of = [&](uint32_t m) -> float {   // sum of |d| over the index list / m (recursive_patchwork.cpp:98-104)
+        auto residual_of = [&](uint32_t m, bool older = false) -> float {   // sum of |d| over the inliers / m (recursive_patchwork.cpp:98-104)
             SweepPrm q; q.a = pl.cx; q.b = pl.cy; q.c = pl.cz; q.d = pl.nx; q.e = pl.ny; q.f = pl.nz;
             Sums6 r;
-            W1_PH(6, m, r = W_SWEEP(nd, m, kSweepDist, 1, q))
+            NodeRef ndr = nd;
+            if (older) ndr.mcur = nd.mprev;             // (server forms: the sweep's elements are the inliers of plane mcur)
+            W1_PH(6, m, r = W_SWEEP(ndr, m, kSweepDist, 1, q))
             cx.addends += m;
             return r.v[0] / (float)m;
         };
@@ -1697,11 +1824,11 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
         } else {
             if (!have_plane) plane_of(count);                    // cs = sums of the final mask, the list holds it
             if (!have_residual) {
-                if (!list_is_final) {                            // rebuild the list from the older mask (bit 1)
+                if (!list_is_final && W != 3) {                  // forms with an index list: rebuild it from the older mask
                     (void)w1_mask_pass(nd, kMaskOlder, mp);
                     wave_sync();
                 }
-                pl.residual = residual_of(count);
+                pl.residual = residual_of(count, !list_is_final && W == 3);  // (batch form: straight from the older mask's plane)
             }
         }
 
@@ -1853,7 +1980,7 @@ __global__ __launch_bounds__(2 * kWave, 4) void patch_fit_srv1_kernel(DevParams 
     const int lane = threadIdx.x & 63;
     if (threadIdx.x < kWave) { srv1_loop(&sv, &sh, &dump); return; }
     uint32_t linear;
-    if (patch_of_item(p, blockIdx.x, lane, linear)) fit_patch<3>(p, sh, linear, lane, &sv, 0);
+    if (patch_of_item(p, blockIdx.x, lane, linear)) fit_patch<(RPW_SRV1_MASKED ? 3 : 4)>(p, sh, linear, lane, &sv, 0);
     if (lane == 0 && *(volatile uint32_t*)&sv.error) atomicOr(p.work + 1, 1u);      // a wait timed out: the host reports it
     srv_leave(&sv, lane);
 }
@@ -1933,12 +2060,12 @@ __global__ __launch_bounds__(kWave * (1 + kSrvFeeders), 4) void srv_loop_bench_k
         for (int r = 0; r < reps; ++r) {
             if (what < 16) {
                 SweepPrm prm; prm.a = 0.25f + acc * 0.0f; prm.b = -0.5f; prm.c = 0.125f; prm.d = 0.0f; prm.e = 0.0f; prm.f = 1.0f;
-                const Sums6 v = srv_chain_sweep(nd, count, what, prm, ring, sv, f);
+                const Sums6 v = srv_chain_sweep<true>(nd, count, what, prm, ring, sv, f);
                 acc += v.v[0];
             } else {
                 MaskPrm mp; mp.cx = 0.0f; mp.cy = 0.0f; mp.cz = acc * 0.0f; mp.nx = 0.0f; mp.ny = 0.0f; mp.nz = 1.0f; mp.thr = 0.6f;
                 if (what == 18) { const MaskOut o = w1_mask_pass(nd, kMaskOlder, mp); acc += (float)o.count; }
-                else { const FusedOut o = srv_fused_pass(nd, what - 16, mp, ring, sv, f); acc += (float)o.count + o.sx * 0.0f; }
+                else { const FusedOut o = srv_fused_pass<false>(nd, what - 16, mp, ring, sv, f); acc += (float)o.count + o.sx * 0.0f; }
             }
         }
         if (lane == 0) { out[node] = acc + (float)sv->error * 1.0e30f; if (node == 0) ticks[0] = __builtin_readcyclecounter() - tick0; }
@@ -1974,12 +2101,12 @@ __global__ __launch_bounds__(2 * kWave, 4) void srv1_loop_bench_kernel(const flo
             srv_wait(pt, start + nslots, seen);
         } else if (what < 16) {
             SweepPrm prm; prm.a = 0.25f + acc * 0.0f; prm.b = -0.5f; prm.c = 0.125f; prm.d = 0.0f; prm.e = 0.0f; prm.f = 1.0f;
-            const Sums6 v = srv_chain_sweep(nd, count, what, prm, ring, &sv, 0);
+            const Sums6 v = srv_chain_sweep<(RPW_SRV1_MASKED != 0)>(nd, count, what, prm, ring, &sv, 0);
             acc += v.v[0];
         } else {
             MaskPrm mp; mp.cx = 0.0f; mp.cy = 0.0f; mp.cz = acc * 0.0f; mp.nx = 0.0f; mp.ny = 0.0f; mp.nz = 1.0f; mp.thr = 0.6f;
             if (what == 18) { const MaskOut o = w1_mask_pass(nd, kMaskOlder, mp); acc += (float)o.count; }
-            else { const FusedOut o = srv_fused_pass(nd, what - 16, mp, ring, &sv, 0); acc += (float)o.count + o.sx * 0.0f; }
+            else { const FusedOut o = srv_fused_pass<(RPW_SRV1_MASKED == 0)>(nd, what - 16, mp, ring, &sv, 0); acc += (float)o.count + o.sx * 0.0f; }
         }
     }
     if (lane == 0) { out[blockIdx.x] = acc + (float)sv.error * 1.0e30f; if (blockIdx.x == 0) ticks[0] = __builtin_readcyclecounter() - tick0; }
