@@ -26,7 +26,8 @@ from rpw_amd import workloads as W
 from parity_util import cfg_pair, assert_frame_parity
 
 frames = [W.c2_hdl64(0), W.c1_test_cloud(1), W.c4_iac_fused(0)[:150000], W.rough_terrain(2, n_clutter=60000)[:140000],
-          W.c1_test_cloud(3, n=67), np.zeros((0, 3), np.float32)]
+          W.c1_test_cloud(3, n=67), np.zeros((0, 3), np.float32),
+          W.c5_dense(0)]             # with num_sectors = 4 its largest node has 106 648 slots: 32-bit index entries in every form
 cases = [dict(max_split_depth=3), dict(max_split_depth=3, max_iter=0), dict(max_split_depth=6, th_dist=0.0005),
          dict(max_split_depth=2, adaptive_seed_height=False, num_sectors=4)]
 n = 0
