@@ -13,12 +13,15 @@
 //                      adds of its sequential sums run on the owner itself (patch_fit1_kernel), on a server wave that adds
 //                      for seven owners at once (patch_fit_srv_kernel, batches), or on a server wave of the patch's own
 //                      (patch_fit_srv1_kernel, launches of few patches) -- see launch_fit and DESIGN.md section 4
+//                      The sweeps over a mask's inliers take them from an index list the fused pass wrote (the first and
+//                      the last form) or expand the mask's bit plane themselves (the batch form: IdxGen).
 //
 // Exactness: every sum the reference accumulates sequentially in binary32 (centroid,
 // covariance, residual, mean distance, variance) is accumulated here in the same order
 // by one lane per accumulator; the other lanes only prepare the addends.
 // Built with -ffp-contract=off; divide and sqrt are correctly rounded.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <cstdlib>
 #include <mutex>
 #include <set>
@@ -1232,6 +1235,8 @@ __device__ __attribute__((noinline)) void srv1_loop(SrvShared* sv, Fit1Shared* s
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) v4u lds_u4;
+    // (no raised priority here: the two waves of this workgroup sit on different SIMDs -- tools/microbench_placement.hip -- and
+    // s_setprio 3 measured 1-2 % slower)
     const int lane = threadIdx.x & 63;
     // lane k < 6 adds row k. The lanes behind them (and the rows a pass does not use) add whatever their row of the ring holds:
     // nobody reads those accumulators, and it keeps every address of the slot a per-lane constant plus a scalar.
