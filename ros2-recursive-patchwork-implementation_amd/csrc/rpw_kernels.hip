@@ -469,10 +469,12 @@ __device__ __forceinline__ void emit_node(const DevParams& p, int tid, int frame
 // ==========================================================================================
 constexpr int kW1Ring = 3;           // ring slots: slot u lives in ring slot u % 3, a compile-time constant inside the loop unrolled by three
 
+constexpr int kPassArgWords = 24;
 struct Fit1Shared {
     __attribute__((aligned(16))) float ring[kRingFloats];              // sweeps: kW1Ring * kSlotFloats floats; fused pass: kFSlots * kFSlotFloats
     uint32_t hist[256];
     uint32_t stk[3 * kStackDepth];
+    __attribute__((aligned(16))) uint32_t args[kPassArgWords];         // arguments of the server forms' pass functions (PassArgs below)
 };
 static_assert(kW1Ring * kSlotFloats <= kRingFloats, "the sweep ring must fit");
 
@@ -1494,19 +1496,67 @@ __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t coun
     return out;
 }
 
+// The server forms' passes are real functions (not inlined), and what does not fit the register convention travels over
+// the STACK: a 24-byte parameter struct costs six dwords per LANE, stored by the caller and loaded by the callee -- 3 KB of
+// scratch traffic per call, two calls per refit, ~6 GB per bench launch that L2 cannot hold between the two ends (its 4 MB
+// turn over in microseconds). So the caller leaves the arguments in its LDS block and passes the block's address.
+// Word layout of the block: 0-13 the node's seven pointers (x, y, z, mnew, mcur, mprev, il), 14 n, 15 count, 16 mode, 17-23 p[0..6].
+// (Packed and unpacked word by word: a struct copied through a cast has its address taken and lives on the stack itself.)
+struct PassArgs { NodeRef nd; uint32_t count; int32_t mode; float p[7]; };
+__device__ __forceinline__ uint32_t pass_args_of(lds_f32* ring)       // the ring is the first member of the owner's Fit1Shared
+{
+    return (uint32_t)(uintptr_t)ring + (uint32_t)offsetof(Fit1Shared, args);
+}
+__device__ __forceinline__ void pass_args_put(lds_f32* ring, const NodeRef& nd, uint32_t count, int mode, const float* p, int np)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4u lds_u4;
+    auto lo = [](const void __attribute__((address_space(1)))* q) { return (uint32_t)(unsigned long long)q; };
+    auto hi = [](const void __attribute__((address_space(1)))* q) { return (uint32_t)((unsigned long long)q >> 32); };
+    auto fw = [&](int k) { return k < np ? __float_as_uint(p[k]) : 0u; };
+    if ((threadIdx.x & 63) == 0) {
+        lds_u4* dst = (lds_u4*)(uintptr_t)pass_args_of(ring);
+        dst[0] = v4u{lo(nd.x), hi(nd.x), lo(nd.y), hi(nd.y)};
+        dst[1] = v4u{lo(nd.z), hi(nd.z), lo(nd.mnew), hi(nd.mnew)};
+        dst[2] = v4u{lo(nd.mcur), hi(nd.mcur), lo(nd.mprev), hi(nd.mprev)};
+        dst[3] = v4u{lo(nd.il), hi(nd.il), nd.n, count};
+        dst[4] = v4u{(uint32_t)mode, fw(0), fw(1), fw(2)};
+        dst[5] = v4u{fw(3), fw(4), fw(5), fw(6)};
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ PassArgs pass_args_get(lds_f32* ring)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4u lds_u4;
+    const lds_u4* src = (const lds_u4*)(uintptr_t)pass_args_of(ring);
+    const v4u w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3], w4 = src[4], w5 = src[5];
+    auto ptr = [](uint32_t l, uint32_t h) { return ((unsigned long long)uni(h) << 32) | (unsigned long long)uni(l); };
+    PassArgs a;
+    a.nd.x = (g_cf32*)ptr(w0.x, w0.y); a.nd.y = (g_cf32*)ptr(w0.z, w0.w); a.nd.z = (g_cf32*)ptr(w1.x, w1.y);
+    a.nd.mnew = (g_u64*)ptr(w1.z, w1.w); a.nd.mcur = (g_u64*)ptr(w2.x, w2.y); a.nd.mprev = (g_u64*)ptr(w2.z, w2.w);
+    a.nd.il = (g_u32*)ptr(w3.x, w3.y); a.nd.n = uni(w3.z); a.count = uni(w3.w);
+    a.mode = (int32_t)uni(w4.x);
+    a.p[0] = uni(__uint_as_float(w4.y)); a.p[1] = uni(__uint_as_float(w4.z)); a.p[2] = uni(__uint_as_float(w4.w));
+    a.p[3] = uni(__uint_as_float(w5.x)); a.p[4] = uni(__uint_as_float(w5.y)); a.p[5] = uni(__uint_as_float(w5.z)); a.p[6] = uni(__uint_as_float(w5.w));
+    return a;
+}
+
 // MASKED (the batch form): the inliers come from the mask plane; else (a server per patch) from the index list the fused pass
 // wrote. Turning mask words into slot numbers costs the feeder ~70 instructions per slot of 64 inliers: among seven feeders
 // and two workgroups per CU they disappear and the bench batch gains 2.4 % from the 2 B per inlier no longer written and
 // read; a LONE feeder issues one instruction per ~6 cycles, its covariance sweep went from 9.7 to 16.7 cycles per inlier
 // (the server waits for it) and a single frame from 2.48 to 3.13 ms -- so the latency form keeps the list.
 template <bool MASKED>
-__device__ __attribute__((noinline)) Sums6 srv_chain_sweep(NodeRef nd_in, uint32_t count, int mode, SweepPrm prm, lds_f32* ring, SrvShared* sv, int f)
+__device__ __attribute__((noinline)) Sums6 srv_chain_sweep_call(lds_f32* ring, SrvShared* sv, int f)
 {
     const int lane = threadIdx.x & 63;
-    const NodeRef nd = uni(nd_in);
-    count = uni(count);
-    prm.a = uni(prm.a); prm.b = uni(prm.b); prm.c = uni(prm.c); prm.d = uni(prm.d); prm.e = uni(prm.e); prm.f = uni(prm.f);
     ring = (lds_f32*)(uintptr_t)uni((uint32_t)(uintptr_t)ring);
+    const PassArgs a = pass_args_get(ring);
+    const NodeRef nd = a.nd;
+    const uint32_t count = a.count;
+    const int mode = a.mode;
+    SweepPrm prm; prm.a = a.p[0]; prm.b = a.p[1]; prm.c = a.p[2]; prm.d = a.p[3]; prm.e = a.p[4]; prm.f = a.p[5];
     sv = uni_ptr(sv);
     const SrvPort pt = srv_port(sv, (int)uni((uint32_t)f));
     Sums6 out;
@@ -1516,7 +1566,7 @@ __device__ __attribute__((noinline)) Sums6 srv_chain_sweep(NodeRef nd_in, uint32
     const bool narrow = nd.n <= 65536u;                // the width the pass that wrote the list used
 #define RPW_SRV_INDEXED(M) (narrow ? srv_sweep_loop<M, (MASKED ? 1 : 2)>(nd, count, prm, ring, pt, lane)   \
                                    : srv_sweep_loop<M, (MASKED ? 3 : 4)>(nd, count, prm, ring, pt, lane))
-    switch (__builtin_amdgcn_readfirstlane(mode)) {
+    switch (mode) {
     case kSweepCov:   return RPW_SRV_INDEXED(kSweepCov);
     case kSweepXYZ:   return RPW_SRV_INDEXED(kSweepXYZ);
     case kSweepDist:  return RPW_SRV_INDEXED(kSweepDist);
@@ -1525,6 +1575,13 @@ __device__ __attribute__((noinline)) Sums6 srv_chain_sweep(NodeRef nd_in, uint32
     default:          return srv_sweep_loop<kSweepVarXY, 0>(nd, count, prm, ring, pt, lane);
     }
 #undef RPW_SRV_INDEXED
+}
+template <bool MASKED>
+__device__ __forceinline__ Sums6 srv_chain_sweep(const NodeRef& nd, uint32_t count, int mode, const SweepPrm& prm, lds_f32* ring, SrvShared* sv, int f)
+{
+    const float p[6] = {prm.a, prm.b, prm.c, prm.d, prm.e, prm.f};
+    pass_args_put(ring, nd, count, mode, p, 6);
+    return srv_chain_sweep_call<MASKED>(ring, sv, f);
 }
 
 // the fused pass's chain, handed to the server: "consume" publishes, "finish" pads, publishes and collects
@@ -1564,22 +1621,30 @@ struct SrvChain {
 };
 
 template <bool LIST>               // LIST: the pass also writes the index list (the latency form's sweeps read it)
-__device__ __attribute__((noinline)) FusedOut srv_fused_pass(NodeRef nd_in, int mode, MaskPrm prm, lds_f32* ring, SrvShared* sv, int f)
+__device__ __attribute__((noinline)) FusedOut srv_fused_pass_call(lds_f32* ring, SrvShared* sv, int f)
 {
     const int lane = threadIdx.x & 63;
-    const NodeRef nd = uni(nd_in);
-    prm.cx = uni(prm.cx); prm.cy = uni(prm.cy); prm.cz = uni(prm.cz); prm.nx = uni(prm.nx); prm.ny = uni(prm.ny); prm.nz = uni(prm.nz);
-    prm.thr = uni(prm.thr);
     ring = (lds_f32*)(uintptr_t)uni((uint32_t)(uintptr_t)ring);
+    const PassArgs a = pass_args_get(ring);
+    const NodeRef nd = a.nd;
+    const int mode = a.mode;
+    MaskPrm prm; prm.cx = a.p[0]; prm.cy = a.p[1]; prm.cz = a.p[2]; prm.nx = a.p[3]; prm.ny = a.p[4]; prm.nz = a.p[5]; prm.thr = a.p[6];
     sv = uni_ptr(sv);
     SrvChain ch;
     ch.begin(srv_port(sv, (int)uni((uint32_t)f)), lane);
     const bool narrow = nd.n <= 65536u;
-    if (uni((uint32_t)mode) == (uint32_t)kMaskPlane)
+    if (mode == kMaskPlane)
         return !LIST ? w1_fused_loop<kMaskPlane, 0>(nd, prm, ring, lane, ch)
                      : (narrow ? w1_fused_loop<kMaskPlane, (LIST ? 2 : 0)>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskPlane, (LIST ? 4 : 0)>(nd, prm, ring, lane, ch));
     return !LIST ? w1_fused_loop<kMaskSeed, 0>(nd, prm, ring, lane, ch)
                  : (narrow ? w1_fused_loop<kMaskSeed, (LIST ? 2 : 0)>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskSeed, (LIST ? 4 : 0)>(nd, prm, ring, lane, ch));
+}
+template <bool LIST>
+__device__ __forceinline__ FusedOut srv_fused_pass(const NodeRef& nd, int mode, const MaskPrm& prm, lds_f32* ring, SrvShared* sv, int f)
+{
+    const float p[7] = {prm.cx, prm.cy, prm.cz, prm.nx, prm.ny, prm.nz, prm.thr};
+    pass_args_put(ring, nd, 0u, mode, p, 7);
+    return srv_fused_pass_call<LIST>(ring, sv, f);
 }
 
 // workgroup set-up and the feeder's good-bye
@@ -1628,9 +1693,14 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
 #define W_SWEEP(ND, M, MODE, INDEXED, PRM) (W == 3 ? srv_chain_sweep<true>(ND, M, MODE, PRM, ring, sv, feeder) : (W == 4 ? srv_chain_sweep<false>(ND, M, MODE, PRM, ring, sv, feeder) : w1_chain_sweep(ND, M, MODE, INDEXED, PRM, ring)))
 #define W_FUSED(ND, MODE, PRM) (W == 3 ? srv_fused_pass<false>(ND, MODE, PRM, ring, sv, feeder) : (W == 4 ? srv_fused_pass<true>(ND, MODE, PRM, ring, sv, feeder) : w1_fused_pass(ND, MODE, PRM, ring)))
 #define W_LEAVE() {}
+    // Everything the node loop carries across its pass calls is wave-uniform; said so (v_readfirstlane), it lives in scalar
+    // registers, whose spills go to lanes of a vector register -- a uniform value left in a VECTOR register across a call is
+    // spilled to scratch memory, 256 bytes per dword and wave, and read back from there call after call.
+    linear = uni(linear);
     const int frame = (int)(linear / (uint32_t)p.P), patch = (int)(linear % (uint32_t)p.P);
-    const PatchDesc pd = p.patches[linear];
-    const uint32_t fo = p.frame_off[frame];
+    PatchDesc pd = p.patches[linear];
+    pd.begin = uni(pd.begin); pd.n = uni(pd.n);
+    const uint32_t fo = uni(p.frame_off[frame]);
 
     W1 cx; cx.sx = p.sx; cx.sy = p.sy; cx.sz = p.sz; cx.il = reinterpret_cast<uint32_t*>(p.ax); cx.sh = &sh;
     cx.base = pd.begin; cx.lane = lane; cx.addends = 0ull;
@@ -1654,11 +1724,11 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
         Sums6 sum;
         W1_PH(1, pd.n, sum = W_SWEEP(root, pd.n, kSweepRange, 0, no_prm))
         cx.addends += pd.n;
-        mean_dist = sum.v[0] / (float)pd.n;
-        root_zmn = sum.v[1]; root_zmx = sum.v[2];      // the patch's z range rides on the same sweep (what the root node's flat test needs)
+        mean_dist = uni(sum.v[0]) / (float)pd.n;
+        root_zmn = uni(sum.v[1]); root_zmx = uni(sum.v[2]);      // the patch's z range rides on the same sweep (what the root node's flat test needs)
     }
-    const float rel_dist = mean_dist / cfg.filtering_radius;
-    const float threshold = cfg.th_dist * (1.0f + 0.2f * rel_dist);
+    const float rel_dist = uni(mean_dist / cfg.filtering_radius);
+    const float threshold = uni(cfg.th_dist * (1.0f + 0.2f * rel_dist));
 
     PatchAcc pa; pa.nodes = 0; pa.splits = 0; pa.maxdepth = 0; pa.ground = 0; pa.iters = 0;
     bool permuted = false;
@@ -1675,8 +1745,8 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
 
     while (sp > 0) {
         --sp;
-        const uint32_t s = stk[3 * sp], n = stk[3 * sp + 1];
-        const int depth = (int)stk[3 * sp + 2];
+        const uint32_t s = uni(stk[3 * sp]), n = uni(stk[3 * sp + 1]);
+        const int depth = (int)uni(stk[3 * sp + 2]);
         wave_sync();
         pa.nodes++;
         if ((uint32_t)depth > pa.maxdepth) pa.maxdepth = (uint32_t)depth;
@@ -1735,7 +1805,7 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
         {   // seed mask + index list + centroid sums of the seeds, one pass
             FusedOut fo_;
             W1_PH(2, n, fo_ = W_FUSED(nd, kMaskSeed, mp))
-            count = fo_.count; cs[0] = fo_.sx; cs[1] = fo_.sy; cs[2] = fo_.sz;
+            count = uni(fo_.count); cs[0] = uni(fo_.sx); cs[1] = uni(fo_.sy); cs[2] = uni(fo_.sz);
             cx.addends += count;
             rotate();
         }
@@ -1757,7 +1827,7 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
             Sums6 r;
             W1_PH(3, 3, r = W_SWEEP(nd, 3, kSweepXYZ, 1, no_prm))
             cx.addends += 3;
-            cs[0] = r.v[0]; cs[1] = r.v[1]; cs[2] = r.v[2];
+            cs[0] = uni(r.v[0]); cs[1] = uni(r.v[1]); cs[2] = uni(r.v[2]);
         }
         wave_sync();
 
@@ -1765,7 +1835,7 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
         PlaneD pl; pl.cx = pl.cy = pl.cz = 0.0f; pl.nx = 0.0f; pl.ny = 0.0f; pl.nz = 1.0f; pl.residual = 3.402823466e+38f;
         auto plane_of = [&](uint32_t m) {               // covariance sweep over the index list + eigenvector
             const float fm = (float)m;
-            SweepPrm c; c.a = cs[0] / fm; c.b = cs[1] / fm; c.c = cs[2] / fm; c.d = c.e = c.f = 0.0f;
+            SweepPrm c; c.a = uni(cs[0] / fm); c.b = uni(cs[1] / fm); c.c = uni(cs[2] / fm); c.d = c.e = c.f = 0.0f;
             Sums6 cv;
             W1_PH(4, m, cv = W_SWEEP(nd, m, kSweepCov, 1, c))
             cx.addends += m;
@@ -1773,7 +1843,7 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
             pl.cx = c.a; pl.cy = c.b; pl.cz = c.c;
             N3 nrm;
             W1_PH(5, 1, nrm = w1_normal(cv.v[0] / fm1, cv.v[1] / fm1, cv.v[2] / fm1, cv.v[3] / fm1, cv.v[4] / fm1, cv.v[5] / fm1))
-            pl.nx = nrm.x; pl.ny = nrm.y; pl.nz = nrm.z;
+            pl.nx = uni(nrm.x); pl.ny = uni(nrm.y); pl.nz = uni(nrm.z);
         };
         auto residual_of = [&](uint32_t m, bool older = false) -> float {   // sum of |d| over the inliers / m (recursive_patchwork.cpp:98-104)
             SweepPrm q; q.a = pl.cx; q.b = pl.cy; q.c = pl.cz; q.d = pl.nx; q.e = pl.ny; q.f = pl.nz;
@@ -1782,7 +1852,7 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
             if (older) ndr.mcur = nd.mprev;             // (server forms: the sweep's elements are the inliers of plane mcur)
             W1_PH(6, m, r = W_SWEEP(ndr, m, kSweepDist, 1, q))
             cx.addends += m;
-            return r.v[0] / (float)m;
+            return uni(uni(r.v[0]) / (float)m);
         };
         int iters = 0;
         int final_bit = 0;
@@ -1796,6 +1866,8 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
             FusedOut mo;                                         // new mask + its index list + its centroid sums
             W1_PH(2, n, mo = W_FUSED(nd, kMaskPlane, mp))
             rotate();
+            mo.count = uni(mo.count); mo.changed = uni(mo.changed); mo.differs_prev = uni(mo.differs_prev);
+            mo.sx = uni(mo.sx); mo.sy = uni(mo.sy); mo.sz = uni(mo.sz);
             const uint32_t newcount = mo.count;
             cx.addends += newcount;
             const bool any_changed = mo.changed != 0, any_differs_prev = mo.differs_prev != 0;

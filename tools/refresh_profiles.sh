@@ -18,8 +18,11 @@ bash tools/collect_sq.sh "$OUT/sq" > "$OUT/sq.log" 2>&1
 # 3. the default bench line (with host path, latency and CPU baseline), the other workloads, variant B, end to end
 python3 bench.py > "$OUT/export/${R}_bench_default.json" 2> "$OUT/bench_default.err"
 python3 bench.py --no-cpu-baseline --no-host-path --end-to-end > "$OUT/export/${R}_bench_end_to_end.json" 2> "$OUT/bench_e2e.err"
-for w in c1 c4 c5 rough3 rough6; do
+for w in c1 rough3 rough6; do
   python3 bench.py --workload $w --steps 12 --warmup 3 --no-host-path > "$OUT/export/${R}_bench_workload_$w.json" 2> "$OUT/bench_$w.err"
+done
+for w in c4 c5; do      # with the host-path legs: these lines also carry `four_batches_in_flight` (few, long patches per wave: it matters here)
+  python3 bench.py --workload $w --steps 12 --warmup 3 --no-cpu-baseline > "$OUT/export/${R}_bench_workload_$w.json" 2> "$OUT/bench_$w.err"
 done
 for w in c2 c4 c5; do
   python3 bench.py --workload $w --max-iter 0 --steps 12 --warmup 3 --no-host-path --no-cpu-baseline > "$OUT/export/${R}_bench_variantB_$w.json" 2> "$OUT/bench_vb_$w.err"
