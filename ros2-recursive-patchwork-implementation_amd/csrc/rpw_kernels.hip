@@ -1110,11 +1110,16 @@ struct SrvPort {
     lds_word* cw;                      // &cons[f]
     lds_f32* accp;                     // acc[f]
     lds_word* err;                     // &error
-};
-__device__ __forceinline__ SrvPort srv_port(SrvShared* sv, int f)
+    uint32_t pub;                      // per lane: where a publish stores -- lane 0 feed[f][0], every other lane a dump word of its own
+};                                     // (in the owner's histogram block, idle during a pass: no exec mask to set up and restore)
+constexpr int kPubDumpAt = 128;        // words of Fit1Shared::hist behind the sweeps' index buffer
+__device__ __forceinline__ SrvPort srv_port(SrvShared* sv, int f, lds_f32* ring)
 {
     SrvPort pt;
     pt.fw = (lds_word*)sv->feed[f]; pt.cw = (lds_word*)&sv->cons[f]; pt.accp = (lds_f32*)sv->acc[f]; pt.err = (lds_word*)&sv->error;
+    const int lane = threadIdx.x & 63;
+    const uint32_t dump = (uint32_t)(uintptr_t)ring + (uint32_t)offsetof(Fit1Shared, hist) + (uint32_t)(kPubDumpAt + lane) * 4u;
+    pt.pub = lane == 0 ? (uint32_t)(uintptr_t)pt.fw : dump;
     return pt;
 }
 __device__ __forceinline__ uint32_t srv_begin(const SrvPort& pt, uint32_t layout, uint32_t rows, int lane)
@@ -1130,7 +1135,7 @@ __device__ __forceinline__ uint32_t srv_begin(const SrvPort& pt, uint32_t layout
 __device__ __forceinline__ void srv_publish(const SrvPort& pt, uint32_t abs_slots, int lane)
 {
     asm volatile("" ::: "memory");
-    if (lane == 0) *(volatile lds_word*)pt.fw = abs_slots;
+    *(volatile lds_word*)(uintptr_t)pt.pub = abs_slots;
     asm volatile("" ::: "memory");
 }
 // until the server has added `need` slots (absolute count); `seen` caches the last value read
@@ -1457,7 +1462,8 @@ __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t coun
     for (int k = 0; k < D; ++k) P[k] = point_of(I[k]);
 #pragma unroll
     for (int k = 0; k < D; ++k) I[k] = index_of((uint32_t)(D + k));
-    auto slot = [&](uint32_t s, X3& P, uint32_t& I) __attribute__((always_inline)) {
+    auto slot = [&](uint32_t s, X3& P, uint32_t& I, auto full) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full)::value;              // all 64 columns of the slot are elements (no padding to write)
         float v[6];
         const X3 q = P;
         if (MODE == kSweepCov) {
@@ -1474,7 +1480,7 @@ __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t coun
         else { const float dx = q.x - prm.a, dy = q.y - prm.b; v[0] = dx * dx; v[1] = dy * dy; }
         if (s >= (uint32_t)kSrvSweepSlots) srv_wait(pt, start + s - (uint32_t)(kSrvSweepSlots - 1), seen);
         lds_f32* dst = ring + (s % (uint32_t)kSrvSweepSlots) * kSlotFloats + lane;
-        const bool live = s * kWave + lane < count;           // columns past the end: -0.0f, the exact additive identity
+        const bool live = FULL || s * kWave + lane < count;   // columns past the end: -0.0f, the exact additive identity
 #pragma unroll
         for (int k = 0; k < K; ++k) dst[k * kLdw] = live ? v[k] : -0.0f;
         srv_publish(pt, start + s + 1u, lane);
@@ -1482,12 +1488,13 @@ __device__ __forceinline__ Sums6 srv_sweep_loop(const NodeRef& nd, uint32_t coun
         I = index_of(s + 2u * (uint32_t)D);
     };
     uint32_t s = 0;
-    for (; s + (uint32_t)D <= nslots; s += (uint32_t)D) {
+    const uint32_t nfull = count / (uint32_t)kWave;               // slots without padding
+    for (; s + (uint32_t)D <= nfull; s += (uint32_t)D) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) slot(s + (uint32_t)k, P[k], I[k]);
+        for (int k = 0; k < D; ++k) slot(s + (uint32_t)k, P[k], I[k], yes());
     }
 #pragma unroll
-    for (int k = 0; k < D - 1; ++k) if (s + (uint32_t)k < nslots) slot(s + (uint32_t)k, P[k], I[k]);
+    for (int k = 0; k < D; ++k) if (s + (uint32_t)k < nslots) slot(s + (uint32_t)k, P[k], I[k], no());
     srv_wait(pt, start + nslots, seen);
     Sums6 out;
 #pragma unroll
@@ -1558,7 +1565,7 @@ __device__ __attribute__((noinline)) Sums6 srv_chain_sweep_call(lds_f32* ring, S
     const int mode = a.mode;
     SweepPrm prm; prm.a = a.p[0]; prm.b = a.p[1]; prm.c = a.p[2]; prm.d = a.p[3]; prm.e = a.p[4]; prm.f = a.p[5];
     sv = uni_ptr(sv);
-    const SrvPort pt = srv_port(sv, (int)uni((uint32_t)f));
+    const SrvPort pt = srv_port(sv, (int)uni((uint32_t)f), ring);
     Sums6 out;
 #pragma unroll
     for (int k = 0; k < 6; ++k) out.v[k] = 0.0f;
@@ -1631,7 +1638,7 @@ __device__ __attribute__((noinline)) FusedOut srv_fused_pass_call(lds_f32* ring,
     MaskPrm prm; prm.cx = a.p[0]; prm.cy = a.p[1]; prm.cz = a.p[2]; prm.nx = a.p[3]; prm.ny = a.p[4]; prm.nz = a.p[5]; prm.thr = a.p[6];
     sv = uni_ptr(sv);
     SrvChain ch;
-    ch.begin(srv_port(sv, (int)uni((uint32_t)f)), lane);
+    ch.begin(srv_port(sv, (int)uni((uint32_t)f), ring), lane);
     const bool narrow = nd.n <= 65536u;
     if (mode == kMaskPlane)
         return !LIST ? w1_fused_loop<kMaskPlane, 0>(nd, prm, ring, lane, ch)
@@ -2168,7 +2175,7 @@ __global__ __launch_bounds__(2 * kWave, 4) void srv1_loop_bench_kernel(const flo
     const unsigned long long tick0 = __builtin_readcyclecounter();
     for (int r = 0; r < reps; ++r) {
         if (what == 7) {                                           // the server alone: `count` addends published at once (whatever the ring holds)
-            const SrvPort pt = srv_port(&sv, 0);
+            const SrvPort pt = srv_port(&sv, 0, ring);
             const uint32_t nslots = (count + kWave - 1) / kWave;
             const uint32_t start = srv_begin(pt, srv_layout((uint32_t)kSlotFloats, (uint32_t)kSrvSweepSlots), 6u, lane);
             uint32_t seen = start;
