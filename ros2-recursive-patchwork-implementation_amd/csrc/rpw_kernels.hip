@@ -683,8 +683,9 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
     const lds_f32* rowp = ring + row * kLdw;
     // one chunk: predicate -> the new mask word (a ballot), compared as a whole with the chunk's word of the current mask
     // (wc) and of the mask before it (wp); list entries and centroid addends of the inliers
-    auto step = [&](const P4& r, uint32_t c, unsigned long long wc, unsigned long long wp, auto full) __attribute__((always_inline)) -> unsigned long long {
+    auto step = [&](const P4& r, uint32_t c, unsigned long long wc, unsigned long long wp, auto full, auto cmp) __attribute__((always_inline)) -> unsigned long long {
         constexpr bool FULL = decltype(full)::value;
+        constexpr bool CMP = decltype(cmp)::value;                 // compare the new word with wc / wp here (the rounds of four do it per lane)
         const uint32_t i = c * kWave + lane;
         const bool ok = FULL || i < n;
         bool in;
@@ -696,7 +697,7 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
         }
         in = in && ok;
         const unsigned long long m = ballot64(in);
-        if (MODE == kMaskPlane) {
+        if (MODE == kMaskPlane && CMP) {
             const unsigned long long valid = FULL ? ~0ull : ((1ull << (n & 63u)) - 1ull);
             changed |= m != (wc & valid);
             differs_prev |= m != (wp & valid);
@@ -725,7 +726,9 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
     // well, and entered straight from the four back-to-back prologue loads they came out as vmcnt(7) where the steady
     // state allows vmcnt(15) -- every chunk then waited for loads issued one chunk earlier.
     // The mask words of a round's four chunks are loaded a round ahead like the points: lane j holds the words of chunk
-    // c + (j & 3), the round copies them to scalars (v_readlane) and requests the next round's at once.
+    // c + (j & 3) and, at the end of the round, the new word of that chunk (the value it stores): the comparisons with the
+    // current mask and the one before it are two 64-bit vector compares per round (sixteen lanes repeat each), where copying
+    // the eight old words to scalars cost sixteen v_readlane and as many scalar compares.
     uint32_t c = 0;
     if (nfull >= 4) {
         P4 r0 = w1_load(nd, 0 * kWave + lane), r1 = w1_load(nd, 1 * kWave + lane), r2 = w1_load(nd, 2 * kWave + lane), r3 = w1_load(nd, 3 * kWave + lane);
@@ -735,45 +738,43 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
             const uint32_t w = cb + ((uint32_t)lane & 3u);
             return plane[w < lastword ? w : lastword];
         };
-        auto lane_word = [](unsigned long long v, int k) -> unsigned long long {
-            return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), k) << 32) |
-                   (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, k);
-        };
-        unsigned long long WC = 0, WP = 0;
+        unsigned long long WC = 0, WP = 0, chg = 0ull, dif = 0ull;
         if (MODE == kMaskPlane) { WC = words_of(nd.mcur, 0); WP = words_of(nd.mprev, 0); }
         auto round = [&]() __attribute__((always_inline)) {
             // (the reloads clamp to the last full chunk: loads past it would be wasted, never wrong)
             const uint32_t b4 = (c + 4) * kWave, b5 = b4 + kWave, b6 = b5 + kWave, b7 = b6 + kWave;
-            unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-            if (MODE == kMaskPlane) {
-                c0 = lane_word(WC, 0); c1 = lane_word(WC, 1); c2 = lane_word(WC, 2); c3 = lane_word(WC, 3);
-                p0 = lane_word(WP, 0); p1 = lane_word(WP, 1); p2 = lane_word(WP, 2); p3 = lane_word(WP, 3);
-                WC = words_of(nd.mcur, c + 4); WP = words_of(nd.mprev, c + 4);
-            }
             ch.reserve(cursor + 4u * kWave);
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long m0 = step(r0, c, c0, p0, yes());     r0 = w1_load(nd, (b4 < lastfull ? b4 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long m1 = step(r1, c + 1, c1, p1, yes()); r1 = w1_load(nd, (b5 < lastfull ? b5 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long m2 = step(r2, c + 2, c2, p2, yes()); r2 = w1_load(nd, (b6 < lastfull ? b6 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long m3 = step(r3, c + 3, c3, p3, yes()); r3 = w1_load(nd, (b7 < lastfull ? b7 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long m0 = step(r0, c, 0ull, 0ull, yes(), no());     r0 = w1_load(nd, (b4 < lastfull ? b4 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long m1 = step(r1, c + 1, 0ull, 0ull, yes(), no()); r1 = w1_load(nd, (b5 < lastfull ? b5 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long m2 = step(r2, c + 2, 0ull, 0ull, yes(), no()); r2 = w1_load(nd, (b6 < lastfull ? b6 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long m3 = step(r3, c + 3, 0ull, 0ull, yes(), no()); r3 = w1_load(nd, (b7 < lastfull ? b7 : lastfull) + lane); __builtin_amdgcn_sched_barrier(0);
             // the round's four new mask words in ONE store: lane j writes the word of chunk c + (j & 3) (sixteen lanes per word)
             {
                 const uint32_t k = (uint32_t)lane & 3u;
                 const unsigned long long lo = (k & 1u) ? m1 : m0, hi = (k & 1u) ? m3 : m2;
-                nd.mnew[c + k] = (k & 2u) ? hi : lo;
+                const unsigned long long mine = (k & 2u) ? hi : lo;
+                nd.mnew[c + k] = mine;
+                if (MODE == kMaskPlane) {
+                    chg |= ballot64(mine != WC);
+                    dif |= ballot64(mine != WP);
+                    WC = words_of(nd.mcur, c + 4); WP = words_of(nd.mprev, c + 4);      // the next round's, needed at its end
+                }
             }
             ch.consume(rowp, cursor >> 6);                            // the slots this round completed
             c += 4;
         };
         round();
         while (c + 4 <= nfull) round();
+        changed |= chg != 0ull;
+        differs_prev |= dif != 0ull;
     }
     for (; c < nfull; ++c) {                                       // up to three full chunks left
         const P4 r = w1_load(nd, c * kWave + lane);
         unsigned long long wc = 0, wp = 0;
         if (MODE == kMaskPlane) { wc = mask_word(nd.mcur, c); wp = mask_word(nd.mprev, c); }
         ch.reserve(cursor + kWave);
-        nd.mnew[c] = step(r, c, wc, wp, yes());                      // (every lane the same word to the same address)
+        nd.mnew[c] = step(r, c, wc, wp, yes(), yes());               // (every lane the same word to the same address)
         ch.consume(rowp, cursor >> 6);
     }
     if (nfull * kWave < n) {                                       // the partial chunk
@@ -782,7 +783,7 @@ __device__ __forceinline__ FusedOut w1_fused_loop(const NodeRef& nd, const MaskP
         unsigned long long wc = 0, wp = 0;
         if (MODE == kMaskPlane) { wc = mask_word(nd.mcur, nfull); wp = mask_word(nd.mprev, nfull); }
         ch.reserve(cursor + kWave);
-        nd.mnew[nfull] = step(r, nfull, wc, wp, no());
+        nd.mnew[nfull] = step(r, nfull, wc, wp, no(), yes());
         ch.consume(rowp, cursor >> 6);
     }
     ch.finish(ring, rowp, cursor, lane);

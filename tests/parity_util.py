@@ -19,7 +19,9 @@ def cfg_pair(**kw):
 
 
 def sort_nodes(nodes, with_frame=False):
-    keys = [nodes["depth"], nodes["start"], nodes["patch"]]
+    # (len breaks the tie between the two children of a split that puts every point on one side: both start at the same
+    # slot at the same depth, one of them with no points -- found by tools/soak.py, seed 73 case 492)
+    keys = [nodes["len"], nodes["depth"], nodes["start"], nodes["patch"]]
     if with_frame:
         keys.append(nodes["frame"])
     return nodes[np.lexsort(keys)]
