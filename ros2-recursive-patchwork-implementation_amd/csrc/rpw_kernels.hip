@@ -1081,6 +1081,11 @@ __device__ __attribute__((noinline)) N3 w1_normal(float a00, float a10, float a1
 // One wave's LDS operations are performed in order, so "addends, then the count" / "accumulator, then cons" need no fence.
 // Waits are polls with s_sleep and a spin limit (a protocol error ends the launch with an error flag, not a hung GPU).
 // ==========================================================================================
+#ifndef RPW_LIST_MAX_SLOTS
+#define RPW_LIST_MAX_SLOTS 0            // batch form: nodes of up to this many slots keep an index list (their passes hit in L2: the list costs no
+#endif                                  // HBM bytes there and saves the mask expansion's instructions); 0 = every node expands its mask planes
+constexpr uint32_t kListMaxSlots = RPW_LIST_MAX_SLOTS;
+static_assert(kListMaxSlots <= 65536u, "nodes with a list in the batch form use 16-bit entries");
 #ifndef RPW_SRV1_MASKED
 #define RPW_SRV1_MASKED 0               // 1: the server-per-patch form takes the inliers from the mask planes too (no index list)
 #endif
@@ -1572,8 +1577,10 @@ __device__ __attribute__((noinline)) Sums6 srv_chain_sweep_call(lds_f32* ring, S
     for (int k = 0; k < 6; ++k) out.v[k] = 0.0f;
     if (count == 0) return out;
     const bool narrow = nd.n <= 65536u;                // the width the pass that wrote the list used
-#define RPW_SRV_INDEXED(M) (narrow ? srv_sweep_loop<M, (MASKED ? 1 : 2)>(nd, count, prm, ring, pt, lane)   \
-                                   : srv_sweep_loop<M, (MASKED ? 3 : 4)>(nd, count, prm, ring, pt, lane))
+    const bool listed = MASKED && kListMaxSlots != 0u && nd.n <= kListMaxSlots;      // a small node of the batch form: 16-bit list
+#define RPW_SRV_INDEXED(M) (listed ? srv_sweep_loop<M, 2>(nd, count, prm, ring, pt, lane)                   \
+                          : (narrow ? srv_sweep_loop<M, (MASKED ? 1 : 2)>(nd, count, prm, ring, pt, lane)   \
+                                    : srv_sweep_loop<M, (MASKED ? 3 : 4)>(nd, count, prm, ring, pt, lane)))
     switch (mode) {
     case kSweepCov:   return RPW_SRV_INDEXED(kSweepCov);
     case kSweepXYZ:   return RPW_SRV_INDEXED(kSweepXYZ);
@@ -1641,10 +1648,11 @@ __device__ __attribute__((noinline)) FusedOut srv_fused_pass_call(lds_f32* ring,
     SrvChain ch;
     ch.begin(srv_port(sv, (int)uni((uint32_t)f), ring), lane);
     const bool narrow = nd.n <= 65536u;
+    const bool listed = !LIST && kListMaxSlots != 0u && nd.n <= kListMaxSlots;      // a small node of the batch form keeps a (16-bit) list
     if (mode == kMaskPlane)
-        return !LIST ? w1_fused_loop<kMaskPlane, 0>(nd, prm, ring, lane, ch)
+        return !LIST ? (listed ? w1_fused_loop<kMaskPlane, 2>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskPlane, 0>(nd, prm, ring, lane, ch))
                      : (narrow ? w1_fused_loop<kMaskPlane, (LIST ? 2 : 0)>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskPlane, (LIST ? 4 : 0)>(nd, prm, ring, lane, ch));
-    return !LIST ? w1_fused_loop<kMaskSeed, 0>(nd, prm, ring, lane, ch)
+    return !LIST ? (listed ? w1_fused_loop<kMaskSeed, 2>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskSeed, 0>(nd, prm, ring, lane, ch))
                  : (narrow ? w1_fused_loop<kMaskSeed, (LIST ? 2 : 0)>(nd, prm, ring, lane, ch) : w1_fused_loop<kMaskSeed, (LIST ? 4 : 0)>(nd, prm, ring, lane, ch));
 }
 template <bool LIST>
@@ -1909,11 +1917,12 @@ __device__ __forceinline__ void fit_patch(const DevParams& p, Fit1Shared& sh, ui
         } else {
             if (!have_plane) plane_of(count);                    // cs = sums of the final mask, the list holds it
             if (!have_residual) {
-                if (!list_is_final && W != 3) {                  // forms with an index list: rebuild it from the older mask
+                const bool node_masked = W == 3 && !(kListMaxSlots != 0u && n <= kListMaxSlots);
+                if (!list_is_final && !node_masked) {            // nodes with an index list: rebuild it from the older mask
                     (void)w1_mask_pass(nd, kMaskOlder, mp);
                     wave_sync();
                 }
-                pl.residual = residual_of(count, !list_is_final && W == 3);  // (batch form: straight from the older mask's plane)
+                pl.residual = residual_of(count, !list_is_final && node_masked);  // (else: straight from the older mask's plane)
             }
         }
 
